@@ -1,0 +1,218 @@
+/* smcmc_detmath.h -- deterministic scalar math + Philox4x32-10 shared by the
+ * HIP kernels (device), the C++ host layer and the CPU oracle.
+ *
+ * Why this exists: the hot path needs log (Metropolis test, reference
+ * TSimpleMCMC.H:455), pow (sigma adaptation, TSimpleMCMC.H:1772-1775), a
+ * N(0,1) draw (TSimpleMCMC.H:719, ROOT TRandom::Gaus) and a U(0,1) draw
+ * (TSimpleMCMC.H:455, ROOT TRandom3::Rndm).  glibc and ocml differ in the last
+ * bit for log/pow/sincos, and ROOT's TRandom3 is one sequential MT19937 behind
+ * a process global, so "same seed => same chain" cannot be defined through
+ * them.  Everything here is built only from IEEE-754 binary64 + - * / sqrt and
+ * explicit fma() plus 32/64-bit integer ops, so that gcc on the host and hipcc
+ * on gfx950 produce bit-identical results when both are compiled with
+ * -ffp-contract=off (tests/test_detmath.py checks the host side against libm to
+ * <= 2 ulp, tests/test_gpu_detmath.py checks device == host bit for bit).
+ *
+ * Draw-slot convention (one chain-step of dimension D):
+ *   Philox key     = (seed_lo, seed_hi)                      [wave-uniform]
+ *   Philox counter = (block, chain_id, step_lo, step_hi | stream<<28)
+ *   word w = 4*block + lane-in-block, w = 0 .. :
+ *     normal for dimension i : Box-Muller pair p = i/2 built from words
+ *                              (2p, 2p+1); even i takes the cosine, odd i the sine
+ *     uniform-proposal dim i : word i
+ *     Metropolis uniform     : word 2*ceil(D/2)   (first word after the pairs)
+ *   a 32-bit word w maps to u = (w + 0.5) * 2^-32 in (0,1), the resolution of
+ *   TRandom3::Rndm.
+ */
+#ifndef SMCMC_DETMATH_H_SEEN
+#define SMCMC_DETMATH_H_SEEN
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define SMCMC_HD __host__ __device__ __forceinline__
+#elif defined(__cplusplus)
+#define SMCMC_HD inline
+#else
+#define SMCMC_HD static inline
+#endif
+
+/* Contraction must be off in every TU that includes this header (build flags
+ * carry -ffp-contract=off); the pragma is a second line of defence for clang. */
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+
+#define SMCMC_FMA(a, b, c) __builtin_fma((a), (b), (c))
+
+/* ---- bit casts -------------------------------------------------------- */
+SMCMC_HD uint64_t smcmc_d2u(double x) {
+    union { double d; uint64_t u; } v; v.d = x; return v.u;
+}
+SMCMC_HD double smcmc_u2d(uint64_t x) {
+    union { double d; uint64_t u; } v; v.u = x; return v.d;
+}
+
+/* ---- Philox4x32-10 (Salmon et al., SC'11; Random123 reference vectors in
+ * tests/test_detmath.py) ------------------------------------------------ */
+#define SMCMC_PHILOX_M0 0xD2511F53u
+#define SMCMC_PHILOX_M1 0xCD9E8D57u
+#define SMCMC_PHILOX_W0 0x9E3779B9u
+#define SMCMC_PHILOX_W1 0xBB67AE85u
+
+typedef struct { uint32_t v[4]; } smcmc_u32x4;
+
+SMCMC_HD smcmc_u32x4 smcmc_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2,
+                                         uint32_t c3, uint32_t k0, uint32_t k1) {
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)SMCMC_PHILOX_M0 * (uint64_t)c0;
+        uint64_t p1 = (uint64_t)SMCMC_PHILOX_M1 * (uint64_t)c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += SMCMC_PHILOX_W0; k1 += SMCMC_PHILOX_W1;
+    }
+    smcmc_u32x4 out; out.v[0] = c0; out.v[1] = c1; out.v[2] = c2; out.v[3] = c3;
+    return out;
+}
+
+/* Counter layout of the draw-slot convention above. */
+#define SMCMC_STREAM_STEP  0u   /* proposal + Metropolis draws of Step()      */
+#define SMCMC_STREAM_START 1u   /* randomised start points (SimpleMCMC.C:147) */
+#define SMCMC_STREAM_HMC   2u   /* momentum / epsilon / accept draws of HMC   */
+
+SMCMC_HD smcmc_u32x4 smcmc_draw_block(uint64_t seed, uint32_t chain, uint64_t step,
+                                      uint32_t block, uint32_t stream) {
+    return smcmc_philox4x32_10(block, chain, (uint32_t)step,
+                               ((uint32_t)(step >> 32) & 0x0FFFFFFFu) | (stream << 28),
+                               (uint32_t)seed, (uint32_t)(seed >> 32));
+}
+
+/* 32-bit word -> u in (0,1): (w + 0.5) * 2^-32, exact in binary64. */
+SMCMC_HD double smcmc_u01(uint32_t w) {
+    return ((double)w + 0.5) * 2.3283064365386962890625e-10;
+}
+
+/* ---- log(x), x > 0 finite normal or subnormal ---------------------------
+ * fdlibm e_log.c scheme: x = 2^k (1+f), sqrt(2)/2 < 1+f < sqrt(2),
+ * s = f/(2+f), log(1+f) = f - hfsq + s (hfsq + R(s^2)).  < 1 ulp. */
+SMCMC_HD double smcmc_log(double x) {
+    const double ln2_hi = 6.93147180369123816490e-01;
+    const double ln2_lo = 1.90821492927058770002e-10;
+    const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01,
+                 Lg3 = 2.857142874366239149e-01, Lg4 = 2.222219843214978396e-01,
+                 Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                 Lg7 = 1.479819860511658591e-01;
+    uint64_t ix = smcmc_d2u(x);
+    int k = 0;
+    if (x == 0.0) return -__builtin_inf();
+    if ((int64_t)ix < 0) return __builtin_nan("");
+    if ((ix >> 52) == 0x7FFu) return x;           /* +inf, nan */
+    if ((ix >> 52) == 0) {                        /* subnormal: scale by 2^54 */
+        x *= 18014398509481984.0; ix = smcmc_d2u(x); k = -54;
+    }
+    uint32_t hx = (uint32_t)(ix >> 32);
+    /* move the split point to sqrt(2)/2: add 0x3ff00000 - 0x3fe6a09e */
+    hx += 0x3ff00000u - 0x3fe6a09eu;
+    k += (int)(hx >> 20) - 0x3ff;
+    hx = (hx & 0x000fffffu) + 0x3fe6a09eu;
+    ix = ((uint64_t)hx << 32) | (ix & 0xffffffffull);
+    double f = smcmc_u2d(ix) - 1.0;
+    double hfsq = 0.5 * f * f;
+    double s = f / (2.0 + f);
+    double z = s * s;
+    double w = z * z;
+    double t1 = w * SMCMC_FMA(w, SMCMC_FMA(w, Lg6, Lg4), Lg2);
+    double t2 = z * SMCMC_FMA(w, SMCMC_FMA(w, SMCMC_FMA(w, Lg7, Lg5), Lg3), Lg1);
+    double R = t2 + t1;
+    double dk = (double)k;
+    return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
+}
+
+/* ---- exp(x), |x| < 700 (fdlibm e_exp.c scheme) --------------------------- */
+SMCMC_HD double smcmc_exp(double x) {
+    const double ln2HI = 6.93147180369123816490e-01;
+    const double ln2LO = 1.90821492927058770002e-10;
+    const double invln2 = 1.44269504088896338700e+00;
+    const double P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03,
+                 P3 = 6.61375632143793436117e-05, P4 = -1.65339022054652515390e-06,
+                 P5 = 4.13813679705723846039e-08;
+    if (x != x) return x;
+    if (x > 709.0) return __builtin_inf();
+    if (x < -745.0) return 0.0;
+    double kf = invln2 * x;
+    /* round to nearest integer without libm: valid for |kf| < 2^51 */
+    kf = (kf + 6755399441055744.0) - 6755399441055744.0;
+    int k = (int)kf;
+    double hi = x - kf * ln2HI;
+    double lo = kf * ln2LO;
+    double r = hi - lo;
+    double t = r * r;
+    double c = r - t * SMCMC_FMA(t, SMCMC_FMA(t, SMCMC_FMA(t, SMCMC_FMA(t, P5, P4), P3), P2), P1);
+    double y = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi);
+    /* scale by 2^k through the exponent field (two steps keep subnormals right) */
+    if (k > -1021 && k < 1023) {
+        return y * smcmc_u2d((uint64_t)(0x3ff + k) << 52);
+    }
+    if (k >= 1023) {
+        return (y * smcmc_u2d((uint64_t)(0x3ff + (k - 1000)) << 52)) * 1.07150860718626732095e+301; /* 2^1000 */
+    }
+    return (y * smcmc_u2d((uint64_t)(0x3ff + (k + 1000)) << 52)) * 9.33263618503218878990e-302;     /* 2^-1000 */
+}
+
+/* pow(x, y) for x > 0 and small |y| (the sigma update uses y <= 1/500,
+ * TSimpleMCMC.H:1772-1775).  exp(y*log x): with |y log x| << 1 the result is
+ * within ~1 ulp of the true power. */
+SMCMC_HD double smcmc_pow_small(double x, double y) {
+    return smcmc_exp(y * smcmc_log(x));
+}
+
+/* ---- sin/cos(2*pi*u), u in [0,1) ----------------------------------------
+ * j = round(4u), g = 4u - j in [-1/2,1/2] (exact for the <= 33-bit u used
+ * here), phi = g*pi/2, fdlibm k_sin/k_cos polynomials on [-pi/4,pi/4], then
+ * the quadrant rotation. */
+SMCMC_HD void smcmc_sincos2pi(double u, double* sn, double* cs) {
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
+                 S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
+                 S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
+                 C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
+                 C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    const double pio2 = 1.57079632679489655800e+00;
+    double t = 4.0 * u;
+    double jf = (t + 6755399441055744.0) - 6755399441055744.0;   /* rint */
+    int j = (int)jf;
+    double g = t - jf;
+    double x = g * pio2;
+    double z = x * x;
+    double ps = SMCMC_FMA(z, SMCMC_FMA(z, SMCMC_FMA(z, SMCMC_FMA(z, SMCMC_FMA(z, S6, S5), S4), S3), S2), S1);
+    double s = SMCMC_FMA(z * x, ps, x);
+    double pc = SMCMC_FMA(z, SMCMC_FMA(z, SMCMC_FMA(z, SMCMC_FMA(z, SMCMC_FMA(z, C6, C5), C4), C3), C2), C1);
+    double hz = 0.5 * z;
+    double c = (1.0 - hz) + (z * z) * pc;
+    switch (j & 3) {
+        case 0:  *sn = s;  *cs = c;  break;
+        case 1:  *sn = c;  *cs = -s; break;
+        case 2:  *sn = -s; *cs = -c; break;
+        default: *sn = -c; *cs = s;  break;
+    }
+}
+
+/* ---- Box-Muller pair from two 32-bit words -------------------------------
+ * n0 = r cos(theta), n1 = r sin(theta), r = sqrt(-2 log u1), theta = 2 pi u2. */
+SMCMC_HD void smcmc_normal_pair(uint32_t w0, uint32_t w1, double* n0, double* n1) {
+    double u1 = smcmc_u01(w0);
+    double u2 = smcmc_u01(w1);
+    double r = __builtin_sqrt(-2.0 * smcmc_log(u1));
+    double sn, cs;
+    smcmc_sincos2pi(u2, &sn, &cs);
+    *n0 = r * cs;
+    *n1 = r * sn;
+}
+
+/* Word index of the Metropolis uniform for dimension D (see header comment). */
+SMCMC_HD uint32_t smcmc_accept_word(uint32_t dim) { return 2u * ((dim + 1u) / 2u); }
+
+#endif

@@ -1,0 +1,344 @@
+"""ctypes loader for the CPU oracle (TEST INFRASTRUCTURE ONLY).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module; the product package must never do so.  See oracle/oracle_core.h for
+what the oracle restates (reference file:line per function) and its parity
+status (PARITY UNPINNED: the reference ships no golden vectors).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "libsmcmc_oracle.so")
+
+LIKE_ISO, LIKE_QUADFORM, LIKE_ROSENBROCK = 0, 1, 2
+MODE_FROZEN, MODE_POOLED = 0, 1
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+_bp = C.POINTER(C.c_uint8)
+
+
+def build(force=False):
+    """Compile the oracle with the committed Makefile (gcc, a second or two)."""
+    srcs = [os.path.join(_HERE, f) for f in
+            ("smcmc_oracle.c", "ensemble_oracle.c", "oracle_core.h", "oracle_linalg.h")]
+    srcs.append(os.path.join(_HERE, "..", "include", "smcmc_detmath.h"))
+    stale = force or not os.path.exists(_LIB_PATH) or any(
+        os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs if os.path.exists(s))
+    if stale:
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        _lib = C.CDLL(_LIB_PATH)
+        _declare(_lib)
+    return _lib
+
+
+def _declare(L):
+    L.oracle_chain_create.restype = C.c_void_p
+    L.oracle_chain_create.argtypes = [C.c_int, C.c_int, _dp, C.c_int, C.c_uint64, C.c_uint32]
+    L.oracle_chain_destroy.argtypes = [C.c_void_p]
+    for name, args in [
+        ("set_gaussian", [C.c_int, C.c_double]), ("set_uniform", [C.c_int, C.c_double, C.c_double]),
+        ("set_correlation", [C.c_int, C.c_int, C.c_double]), ("set_covariance_frozen", [C.c_int]),
+        ("set_covariance_window", [C.c_int]), ("set_covariance_deweight", [C.c_double]),
+        ("set_acceptance_window", [C.c_double]), ("set_acceptance_deweight", [C.c_double]),
+        ("set_acceptance_rigidity", [C.c_double]), ("set_target_acceptance", [C.c_double]),
+        ("set_next_update", [C.c_double]), ("set_sigma", [C.c_double]),
+        ("set_step_rms_window", [C.c_int]), ("set_scan_dimension", [C.c_int]),
+        ("force_step", [_dp]), ("update_proposal", []), ("reset_proposal", []),
+    ]:
+        f = getattr(L, "oracle_chain_" + name)
+        f.restype = None
+        f.argtypes = [C.c_void_p] + args
+    L.oracle_chain_start_api.restype = C.c_int
+    L.oracle_chain_start_api.argtypes = [C.c_void_p, _dp]
+    L.oracle_chain_step_api.restype = C.c_int
+    L.oracle_chain_step_api.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.oracle_chain_run.restype = None
+    L.oracle_chain_run.argtypes = [C.c_void_p, C.c_int, C.c_int, _bp, _dp, _dp, _dp, _dp, _ip, _ip, _dp]
+    L.oracle_chain_run_moments.restype = None
+    L.oracle_chain_run_moments.argtypes = [C.c_void_p, C.c_int, _dp, _dp, C.POINTER(C.c_int)]
+    for name in ("accepted", "proposed", "center", "covariance", "decomposition", "scalars"):
+        f = getattr(L, "oracle_chain_get_" + name)
+        f.restype = None
+        f.argtypes = [C.c_void_p, _dp]
+
+    L.oracle_log_v.argtypes = [C.c_int, _dp, _dp]
+    L.oracle_exp_v.argtypes = [C.c_int, _dp, _dp]
+    L.oracle_pow_small_v.argtypes = [C.c_int, _dp, _dp, _dp]
+    L.oracle_sincos2pi_v.argtypes = [C.c_int, _dp, _dp, _dp]
+    L.oracle_philox.argtypes = [C.c_uint32] * 6 + [C.POINTER(C.c_uint32)]
+    L.oracle_step_draws.argtypes = [C.c_uint64, C.c_uint32, C.c_uint64, C.c_int, _dp, _dp]
+    L.oracle_cholesky.restype = C.c_int
+    L.oracle_cholesky.argtypes = [C.c_int, _dp, _dp]
+    L.oracle_eigen.argtypes = [C.c_int, _dp, _dp, _dp]
+    L.oracle_loglike.restype = C.c_double
+    L.oracle_loglike.argtypes = [C.c_int, C.c_int, _dp, _dp]
+    L.oracle_dummy_error_matrix.restype = C.c_int
+    L.oracle_dummy_error_matrix.argtypes = [C.c_int, _dp, _dp]
+
+    L.oracle_ensemble_create.restype = C.c_void_p
+    L.oracle_ensemble_create.argtypes = [C.c_int, C.c_int, C.c_int, _dp, C.c_int, C.c_uint64, C.c_uint32,
+                                         C.c_int, C.c_int]
+    L.oracle_ensemble_destroy.argtypes = [C.c_void_p]
+    for name, args in [
+        ("set_gaussian", [C.c_int, C.c_double]), ("set_uniform", [C.c_int, C.c_double, C.c_double]),
+        ("set_correlation", [C.c_int, C.c_int, C.c_double]), ("set_covariance_window", [C.c_double]),
+        ("set_covariance_deweight", [C.c_double]), ("set_acceptance_window", [C.c_double]),
+        ("set_acceptance_deweight", [C.c_double]), ("set_acceptance_rigidity", [C.c_double]),
+        ("set_target_acceptance", [C.c_double]), ("set_step_rms_window", [C.c_int]),
+        ("set_sigma", [C.c_double]), ("step", [C.c_int, C.c_int]), ("reduce_moments", [_dp]),
+        ("apply_moments", [_dp]), ("sync", []), ("get_x", [_dp]), ("get_lane_f64", [C.c_int, _dp]),
+        ("get_lane_i32", [C.c_int, _ip]), ("get_last_accept", [_bp]), ("get_center", [_dp]),
+        ("get_covariance", [_dp]), ("get_decomposition", [_dp]), ("get_shared", [_dp]),
+    ]:
+        f = getattr(L, "oracle_ensemble_" + name)
+        f.restype = None
+        f.argtypes = [C.c_void_p] + args
+    L.oracle_ensemble_start.restype = C.c_int
+    L.oracle_ensemble_start.argtypes = [C.c_void_p, _dp, C.c_int]
+
+
+def _p(a):
+    return a.ctypes.data_as(_dp)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def dummy_error_matrix(dim):
+    """TDummyLogLikelihood::Init() for a general D: (Covariance, Error)."""
+    cov = np.zeros((dim, dim))
+    err = np.zeros((dim, dim))
+    ok = lib().oracle_dummy_error_matrix(dim, _p(cov), _p(err))
+    assert ok
+    return cov, err
+
+
+def like_params(kind, dim, params=None):
+    if params is not None:
+        return _f64(params).ravel()
+    if kind == LIKE_QUADFORM:
+        return dummy_error_matrix(dim)[1].ravel()
+    if kind == LIKE_ROSENBROCK:
+        return np.array([100.0])
+    return np.zeros(0)
+
+
+SCALAR_NAMES = ["accepted_logl", "proposed_logl", "sigma", "acceptance", "acceptance_trials",
+                "acceptance_window", "rigidity", "target", "sigma_trace", "cov_trials",
+                "central_trials", "cov_window", "trials", "successes", "next_update", "total_steps",
+                "like_count", "step_rms", "update_count", "last_update_path", "failed",
+                "step_rms_trials"]
+
+
+class Chain:
+    """One reference chain: sMCMC::TSimpleMCMC<L, TProposeAdaptiveStep>."""
+
+    def __init__(self, dim, kind=LIKE_ISO, params=None, seed=20240607, chain_id=0):
+        self.dim = dim
+        prm = like_params(kind, dim, params)
+        self._h = lib().oracle_chain_create(dim, kind, _p(prm) if prm.size else None, prm.size, seed, chain_id)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().oracle_chain_destroy(self._h)
+            self._h = None
+
+    def __getattr__(self, name):
+        if name.startswith("set_") or name in ("update_proposal", "reset_proposal"):
+            f = getattr(lib(), "oracle_chain_" + name)
+            return lambda *a: f(self._h, *a)
+        raise AttributeError(name)
+
+    def force_step(self, p):
+        lib().oracle_chain_force_step(self._h, _p(_f64(p)))
+
+    def start(self, x0):
+        return bool(lib().oracle_chain_start_api(self._h, _p(_f64(x0))))
+
+    def step(self, save=False, metropolis=0):
+        return bool(lib().oracle_chain_step_api(self._h, int(save), metropolis))
+
+    def run(self, nsteps, metropolis=0):
+        out = dict(accepted=np.zeros(nsteps, np.uint8), logl_proposed=np.zeros(nsteps),
+                   logl_accepted=np.zeros(nsteps), sigma=np.zeros(nsteps), acceptance=np.zeros(nsteps),
+                   trials=np.zeros(nsteps, np.int32), successes=np.zeros(nsteps, np.int32),
+                   step_rms=np.zeros(nsteps))
+        lib().oracle_chain_run(self._h, nsteps, metropolis, out["accepted"].ctypes.data_as(_bp),
+                               _p(out["logl_proposed"]), _p(out["logl_accepted"]), _p(out["sigma"]),
+                               _p(out["acceptance"]), out["trials"].ctypes.data_as(_ip),
+                               out["successes"].ctypes.data_as(_ip), _p(out["step_rms"]))
+        return out
+
+    def run_quiet(self, nsteps):
+        lib().oracle_chain_run(self._h, nsteps, 0, None, None, None, None, None, None, None, None)
+
+    def run_moments(self, nsteps):
+        s = np.zeros(self.dim)
+        ss = np.zeros((self.dim, self.dim))
+        na = C.c_int(0)
+        lib().oracle_chain_run_moments(self._h, nsteps, _p(s), _p(ss), C.byref(na))
+        return s, ss, na.value
+
+    def _vec(self, name, n):
+        out = np.zeros(n)
+        getattr(lib(), "oracle_chain_get_" + name)(self._h, _p(out))
+        return out
+
+    accepted = property(lambda self: self._vec("accepted", self.dim))
+    proposed = property(lambda self: self._vec("proposed", self.dim))
+    center = property(lambda self: self._vec("center", self.dim))
+    covariance = property(lambda self: self._vec("covariance", self.dim * self.dim).reshape(self.dim, self.dim))
+    decomposition = property(lambda self: self._vec("decomposition", self.dim * self.dim).reshape(self.dim, self.dim))
+
+    @property
+    def scalars(self):
+        return dict(zip(SCALAR_NAMES, self._vec("scalars", len(SCALAR_NAMES))))
+
+
+LANE_F64 = {"logl": 0, "sigma": 1, "acceptance": 2, "acceptance_trials": 3, "rigidity": 4,
+            "step_rms": 5, "logl_proposed": 6}
+LANE_I32 = {"trials": 0, "successes": 1, "next_update": 2, "naccept": 3, "step_rms_trials": 4}
+SHARED_NAMES = ["sigma_trace", "cov_trials", "central_trials", "cov_window", "acceptance_window",
+                "target", "total_steps", "update_count", "last_update_path", "failed",
+                "pending_sigma_scale", "decomp_full"]
+
+
+class Ensemble:
+    """The many-chain engine semantics, restated on the CPU."""
+
+    def __init__(self, nchains, dim, kind=LIKE_ISO, params=None, seed=20240607, chain_offset=0,
+                 mode=MODE_POOLED, exact=True):
+        self.nchains, self.dim = nchains, dim
+        prm = like_params(kind, dim, params)
+        self._h = lib().oracle_ensemble_create(nchains, dim, kind, _p(prm) if prm.size else None, prm.size,
+                                               seed, chain_offset, mode, int(exact))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().oracle_ensemble_destroy(self._h)
+            self._h = None
+
+    def __getattr__(self, name):
+        if name.startswith("set_") or name == "sync":
+            f = getattr(lib(), "oracle_ensemble_" + name)
+            return lambda *a: f(self._h, *a)
+        raise AttributeError(name)
+
+    def start(self, x0):
+        x0 = _f64(x0)
+        broadcast = int(x0.ndim == 1)
+        if not broadcast:
+            assert x0.shape == (self.dim, self.nchains)
+        return bool(lib().oracle_ensemble_start(self._h, _p(x0), broadcast))
+
+    def step(self, nsteps=1, metropolis=0):
+        lib().oracle_ensemble_step(self._h, nsteps, metropolis)
+
+    @property
+    def npacked(self):
+        return (self.dim + 1) * (self.dim + 2) // 2
+
+    def reduce_moments(self):
+        m = np.zeros(self.npacked)
+        lib().oracle_ensemble_reduce_moments(self._h, _p(m))
+        return m
+
+    def apply_moments(self, m):
+        lib().oracle_ensemble_apply_moments(self._h, _p(_f64(m)))
+
+    @property
+    def x(self):
+        out = np.zeros((self.dim, self.nchains))
+        lib().oracle_ensemble_get_x(self._h, _p(out))
+        return out
+
+    def lane(self, name):
+        if name in LANE_F64:
+            out = np.zeros(self.nchains)
+            lib().oracle_ensemble_get_lane_f64(self._h, LANE_F64[name], _p(out))
+            return out
+        if name == "last_accept":
+            out = np.zeros(self.nchains, np.uint8)
+            lib().oracle_ensemble_get_last_accept(self._h, out.ctypes.data_as(_bp))
+            return out
+        out = np.zeros(self.nchains, np.int32)
+        lib().oracle_ensemble_get_lane_i32(self._h, LANE_I32[name], out.ctypes.data_as(_ip))
+        return out
+
+    def _vec(self, name, n):
+        out = np.zeros(n)
+        getattr(lib(), "oracle_ensemble_get_" + name)(self._h, _p(out))
+        return out
+
+    center = property(lambda self: self._vec("center", self.dim))
+    covariance = property(lambda self: self._vec("covariance", self.dim ** 2).reshape(self.dim, self.dim))
+    decomposition = property(lambda self: self._vec("decomposition", self.dim ** 2).reshape(self.dim, self.dim))
+
+    @property
+    def shared(self):
+        return dict(zip(SHARED_NAMES, self._vec("shared", len(SHARED_NAMES))))
+
+
+# ---- vectorised detmath (tests/test_detmath.py) ----
+def det_log(x):
+    x = _f64(x); out = np.empty_like(x); lib().oracle_log_v(x.size, _p(x), _p(out)); return out
+
+
+def det_exp(x):
+    x = _f64(x); out = np.empty_like(x); lib().oracle_exp_v(x.size, _p(x), _p(out)); return out
+
+
+def det_pow_small(x, y):
+    x = _f64(x); y = _f64(y); out = np.empty_like(x)
+    lib().oracle_pow_small_v(x.size, _p(x), _p(y), _p(out)); return out
+
+
+def det_sincos2pi(u):
+    u = _f64(u); s = np.empty_like(u); c = np.empty_like(u)
+    lib().oracle_sincos2pi_v(u.size, _p(u), _p(s), _p(c)); return s, c
+
+
+def philox(ctr, key):
+    out = (C.c_uint32 * 4)()
+    lib().oracle_philox(*[int(v) for v in ctr], *[int(v) for v in key], out)
+    return [int(v) for v in out]
+
+
+def step_draws(seed, chain, step, dim):
+    n = np.zeros(dim); u = C.c_double(0)
+    lib().oracle_step_draws(seed, chain, step, dim, _p(n), C.byref(u))
+    return n, u.value
+
+
+def cholesky(A):
+    A = _f64(A); U = np.zeros_like(A)
+    ok = lib().oracle_cholesky(A.shape[0], _p(A), _p(U))
+    return bool(ok), U
+
+
+def eigen(A):
+    A = _f64(A); n = A.shape[0]; vec = np.zeros_like(A); val = np.zeros(n)
+    lib().oracle_eigen(n, _p(A), _p(vec), _p(val))
+    return val, vec
+
+
+def loglike(kind, p, params=None):
+    p = _f64(p); prm = like_params(kind, p.size, params)
+    return lib().oracle_loglike(kind, p.size, _p(p), _p(prm) if prm.size else None)

@@ -1,0 +1,155 @@
+#!/usr/bin/env python3
+"""Headline benchmark: chain-steps/s of the TSimpleMCMC::Step() path on MI355X.
+
+Workload (BASELINE.json configs[1]): README-form TDummyLogLikelihood (the
+synthetic iso-Gaussian, README.md:57-66), D = 50, 65 536 chains per GPU,
+TProposeAdaptiveStep with the covariance pooled over all chains, reference
+arithmetic order (EXACT).  One bench "step" = one adaptation window: 256
+ensemble steps in ONE kernel launch, then the pooled moment reduction, the
+all-reduce over ranks (RCCL, only when --gpus > 1) and UpdateProposal.  Every
+chain-step does the full reference work: D normals through U, logL, Metropolis
+test, scalar adaptation and the second-moment fold.
+
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+DIM = 50
+CHAINS_PER_GPU = 65536
+WINDOW = 256                      # ensemble steps per launch / adaptation window
+BYTES_PER_CHAIN_STEP = 16 * DIM + 16   # state round-trip model
+HBM_PEAK_GBPS = 8000.0
+
+
+def cpu_baseline(seconds=12.0):
+    """The oracle's single reference chain (oracle_chain, D=50 iso-Gaussian,
+    adaptive) timed on one host core for a bounded sample."""
+    from oracle import oracle as O
+    O.build()
+    c = O.Chain(DIM)
+    c.start(np.zeros(DIM))
+    c.run_quiet(20000)            # warm up / first adaptation
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        c.run_quiet(50000)
+        n += 50000
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "chain-steps/s", "cores": 1, "kind": "port",
+            "sample": f"{n} Step() calls of one D={DIM} iso-Gaussian chain, TProposeAdaptiveStep, "
+                      f"oracle/oracle_core.h compiled gcc -O2 (no -march), {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--chains", type=int, default=CHAINS_PER_GPU)
+    ap.add_argument("--window", type=int, default=WINDOW)
+    ap.add_argument("--fast", action="store_true", help="fused multiply-add arithmetic (not the headline)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from smcmc_amd_loader import load_package
+    pkg = load_package()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+
+    stream = torch.cuda.current_stream()
+    eng = pkg.Engine(DIM, args.chains, likelihood=pkg.LIKE_ISO_GAUSS, seed=20240607,
+                     chain_offset=rank * args.chains, device=local, mode=pkg.MODE_POOLED,
+                     exact=not args.fast, stream=stream.cuda_stream)
+    assert eng.Start(np.zeros(DIM))
+    mbuf = torch.zeros(eng.moments_size, dtype=torch.float64, device="cuda")
+
+    kernel_ms = []
+
+    def window(timed):
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+        eng.Step(args.window)
+        if timed:
+            e1.record(stream)
+            kernel_ms.append((e0, e1))
+        eng.reduce_moments()
+        if world > 1:
+            eng.export_moments(mbuf.data_ptr())
+            dist.all_reduce(mbuf)
+            eng.import_moments(mbuf.data_ptr())
+        eng.apply_moments()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        window(False)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        window(True)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    chain_steps = float(args.chains) * world * args.window * args.steps
+    value = chain_steps / dt
+    kms = float(np.mean([a.elapsed_time(b) for a, b in kernel_ms]))
+    per_launch = float(args.chains) * args.window
+    achieved = per_launch * BYTES_PER_CHAIN_STEP / (kms * 1e-3) / 1e9
+
+    naccept = eng.lane("naccept").astype(np.float64)
+    total_steps = eng.get_param("TOTAL_STEPS")
+    out = {
+        "metric": "chain-steps/s on D=50 TDummyLogLikelihood, 65 536 chains; ESS/s + accept rate",
+        "value": value, "unit": "chain-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "TDummyLogLikelihood README form (iso-Gaussian) D=50, 65536 chains/GPU, "
+                               "TProposeAdaptiveStep pooled covariance, window=%d steps/launch" % args.window,
+                   "dim": DIM, "chains_per_gpu": args.chains, "window": args.window,
+                   "arithmetic": "fused" if args.fast else "reference-order", "seed": 20240607},
+        "accept_rate": float(naccept.sum() / (total_steps * args.chains)),
+        "mean_sigma": float(eng.lane("sigma").mean()),
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                     "kernel": "step_kernel<50,ISO,%s,tri,moments>" % ("fused" if args.fast else "exact"),
+                     "kernel_ms": kms, "bytes_per_chain_step": BYTES_PER_CHAIN_STEP,
+                     "chain_steps_per_launch": per_launch},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,193 @@
+/* smcmc.h -- C ABI of the MI355X many-chain adaptive Metropolis engine.
+ *
+ * Drop-in boundary for ONE path of ClarkMcGrew/root-simple-mcmc: the
+ * sMCMC::TSimpleMCMC<L, sMCMC::TProposeAdaptiveStep>::Step() loop.  The reference
+ * exposes no FFI; its boundary is the C++ template surface of TSimpleMCMC.H:185-590
+ * and the TProposeAdaptiveStep public methods (TSimpleMCMC.H:732-1003).  The
+ * host-side mirror of that surface (include/TSimpleMCMC_amd.H and the Python
+ * package root-simple-mcmc_amd/) is written on top of exactly these entry
+ * points; each one names the reference member it stands behind.
+ *
+ * Conventions: every function returns an smcmc_status (0 = ok); no exception
+ * crosses the ABI; vectors over chains are laid out [dim][chain] (chain index
+ * fastest), host buffers are caller-owned, one engine per (device, stream),
+ * calls on one engine are serialised by the caller.  Kernel launches are
+ * asynchronous on the engine's stream; every smcmc_read_* / smcmc_get_* /
+ * smcmc_apply_moments call synchronises that stream first.
+ */
+#ifndef SMCMC_H_SEEN
+#define SMCMC_H_SEEN
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct smcmc_engine smcmc_engine;
+
+typedef enum {
+    SMCMC_OK = 0,
+    SMCMC_ERR_INVALID = 1,      /* std::invalid_argument in the reference (TSimpleMCMC.H:373,813,1153) */
+    SMCMC_ERR_LOGIC = 2,        /* std::logic_error (TSimpleMCMC.H:666,673,1575) */
+    SMCMC_ERR_RUNTIME = 3,      /* std::runtime_error (TSimpleMCMC.H:1027,1385,1479) */
+    SMCMC_ERR_BAD_START = 4,    /* Start() returned false (TSimpleMCMC.H:265-268) */
+    SMCMC_ERR_UNSUPPORTED = 5,  /* configuration the HIP path does not cover; never a CPU fallback */
+    SMCMC_ERR_HIP = 6,          /* a HIP runtime call failed (smcmc_last_error has the text) */
+    SMCMC_ERR_NO_DEVICE = 7
+} smcmc_status;
+
+/* Likelihood functors with a device implementation (the `UserLikelihood`
+ * template argument of TSimpleMCMC.H:185). */
+typedef enum {
+    SMCMC_LIKE_ISO_GAUSS = 0,   /* README.md:57-66 / TSimpleMCMC.H:111-120: logL = sum -0.5 p_i^2 */
+    SMCMC_LIKE_QUADFORM = 1,    /* TDummyLogLikelihood.H:21-31; params = Error matrix, dim*dim row-major */
+    SMCMC_LIKE_ROSENBROCK = 2   /* THardLogLikelihood.H:57-67; params = {ROSEN_B}, default 100 */
+} smcmc_likelihood;
+
+/* How the proposal covariance adapts over the ensemble. */
+typedef enum {
+    SMCMC_MODE_FROZEN = 0,  /* SetCovarianceFrozen(true) (TSimpleMCMC.H:937): every chain is an
+                               independent reference chain on the shared, fixed decomposition */
+    SMCMC_MODE_POOLED = 1   /* running centre/covariance (TSimpleMCMC.H:1780-1820) pooled over all
+                               chains through batch moments; UpdateProposal at every smcmc_sync */
+} smcmc_mode;
+
+/* Scalar knobs / observables of TProposeAdaptiveStep and TSimpleMCMC. */
+typedef enum {
+    SMCMC_P_COVARIANCE_WINDOW = 0,      /* Set/GetCovarianceWindow        TSimpleMCMC.H:914-915 */
+    SMCMC_P_COVARIANCE_DEWEIGHT = 1,    /* SetCovarianceUpdateDeweighting :927 */
+    SMCMC_P_ACCEPTANCE_WINDOW = 2,      /* Set/GetAcceptanceWindow        :982-983 */
+    SMCMC_P_ACCEPTANCE_DEWEIGHT = 3,    /* SetAcceptanceUpdateDeweighting :987 */
+    SMCMC_P_ACCEPTANCE_RIGIDITY = 4,    /* Set/GetAcceptanceRigidity      :1002-1003 (set: all chains) */
+    SMCMC_P_TARGET_ACCEPTANCE = 5,      /* Set/GetTargetAcceptance        :977-978 */
+    SMCMC_P_SIGMA = 6,                  /* Get/SetSigma                   :770,775 (set: all chains; get: chain 0) */
+    SMCMC_P_MAXIMUM_CORRELATION = 7,    /* SetMaximumCorrelation          :909 */
+    SMCMC_P_STEP_RMS_WINDOW = 8,        /* SetStepRMSWindow               :511 */
+    SMCMC_P_NEXT_UPDATE = 9,            /* Set/GetNextUpdate              :992-993 (FROZEN: all chains) */
+    SMCMC_P_COVARIANCE_TRIALS = 10,     /* Get/SetCovarianceTrials        :942,947 */
+    SMCMC_P_CENTER_TRIALS = 11,         /* Get/SetEstimatedCenterTrials   :741,747 */
+    SMCMC_P_COVARIANCE_TRACE = 12,      /* GetCovarianceTrace             :961 (read only) */
+    SMCMC_P_TOTAL_STEPS = 13,           /* fTotalSteps                    :554 (read only) */
+    SMCMC_P_SIGMA_TRACE = 14,           /* fSigmaTrace                    :1960 (read only) */
+    SMCMC_P_UPDATE_COUNT = 15,          /* number of UpdateProposal calls (diagnostic, read only) */
+    SMCMC_P_LAST_UPDATE_PATH = 16,      /* 0 Cholesky 1 conditioned 2 eigen 3 emergency 4 reset (read only) */
+    SMCMC_P_EXACT_ARITHMETIC = 17,      /* 1: reference operation order (default); 0: fused multiply-add */
+    SMCMC_P_COUNT_
+} smcmc_param;
+
+/* Per-chain double fields (smcmc_read_lane_f64). */
+typedef enum {
+    SMCMC_LANE_LOGL = 0,            /* fAcceptedLogLikelihood  TSimpleMCMC.H:568 */
+    SMCMC_LANE_SIGMA = 1,           /* fSigma                  :1955 */
+    SMCMC_LANE_ACCEPTANCE = 2,      /* fAcceptance             :1934 */
+    SMCMC_LANE_ACCEPTANCE_TRIALS = 3,
+    SMCMC_LANE_RIGIDITY = 4,
+    SMCMC_LANE_LAST_VALUE = 5,      /* fLastValue              :1838 */
+    SMCMC_LANE_LAST_X0 = 6,         /* fLastPoint[0]           :1835 */
+    SMCMC_LANE_STEP_RMS = 7,        /* fStepRMS                :580 */
+    SMCMC_LANE_LOGL_PROPOSED = 8,   /* fProposedLogLikelihood  :589 */
+    SMCMC_LANE_F64_COUNT_
+} smcmc_lane_f64;
+
+/* Per-chain int32 fields (smcmc_read_lane_i32). */
+typedef enum {
+    SMCMC_LANE_TRIALS = 0,          /* fTrials      :1922 */
+    SMCMC_LANE_SUCCESSES = 1,       /* fSuccesses   :1926 */
+    SMCMC_LANE_NEXT_UPDATE = 2,     /* fNextUpdate  :1930 */
+    SMCMC_LANE_NACCEPT = 3,         /* sum of Step() return values */
+    SMCMC_LANE_STEP_RMS_TRIALS = 4, /* fStepRMSTrials :583 */
+    SMCMC_LANE_LAST_ACCEPT = 5,     /* Step() return value of the latest step */
+    SMCMC_LANE_I32_COUNT_
+} smcmc_lane_i32;
+
+/* ---- lifetime ---------------------------------------------------------- */
+/* TSimpleMCMC constructor (TSimpleMCMC.H:203) + SetDim (:786).  chain_offset is the
+ * global id of local chain 0 (the Philox stream of chain c is keyed on
+ * chain_offset + c), so an ensemble sharded over ranks draws the same numbers as
+ * the unsharded one.  Fails with SMCMC_ERR_NO_DEVICE when no GPU is visible. */
+int smcmc_create(int dim, int nchains, int likelihood, uint64_t seed, uint32_t chain_offset,
+                 int device, smcmc_engine** out);
+int smcmc_destroy(smcmc_engine* h);
+const char* smcmc_last_error(const smcmc_engine* h);
+const char* smcmc_status_string(int status);
+/* Build facts, callable without a GPU: library version, compiled kernel families. */
+int smcmc_version(void);
+int smcmc_max_register_dim(void);
+/* hipStream_t to launch on (NULL = default stream). */
+int smcmc_set_stream(smcmc_engine* h, void* hip_stream);
+
+/* ---- configuration (before smcmc_start) -------------------------------- */
+int smcmc_set_likelihood_params(smcmc_engine* h, const double* params, int count);   /* GetLogLikelihood() :239 */
+int smcmc_set_mode(smcmc_engine* h, int mode);
+int smcmc_set_gaussian(smcmc_engine* h, int dim, double sigma);                      /* SetGaussian :855 */
+int smcmc_set_uniform(smcmc_engine* h, int dim, double minimum, double maximum);     /* SetUniform :833 */
+int smcmc_set_correlation(smcmc_engine* h, int dim1, int dim2, double correlation);  /* SetCorrelation :883 */
+int smcmc_reset_correlations(smcmc_engine* h);                                       /* ResetCorrelations :874 */
+int smcmc_set_param(smcmc_engine* h, int which, double value);
+int smcmc_get_param(smcmc_engine* h, int which, double* value);
+
+/* ---- the chain ---------------------------------------------------------- */
+/* Start (TSimpleMCMC.H:246-276) + InitializeState (:1679-1714).  x0 is [dim] when
+ * broadcast != 0, else [dim][nchains].  SMCMC_ERR_BAD_START when any chain's start
+ * has a non-finite or < -0.999999E+10 log-likelihood. */
+int smcmc_start(smcmc_engine* h, const double* x0, int broadcast);
+/* nsteps x Step(save=false, metropolis) for every chain (TSimpleMCMC.H:370-496):
+ * one kernel launch, state stays in registers between the steps. */
+int smcmc_step(smcmc_engine* h, int nsteps, int metropolis);
+/* Same, and after every `stride`-th step writes the accepted point and its
+ * log-likelihood (the `Accepted` / `LogLikelihood` branches, TSimpleMCMC.H:208-210)
+ * into caller-owned DEVICE buffers save_x[slot][dim_padded][nchains_padded] (rows
+ * >= dim are zero), save_logl[slot][nchains_padded]; slots = nsteps / stride. */
+int smcmc_step_save(smcmc_engine* h, int nsteps, int metropolis, int stride,
+                    double* save_x_device, double* save_logl_device);
+/* ForceStep (TSimpleMCMC.H:811-817): the next step of every chain proposes
+ * exactly `point` ([dim] broadcast or [dim][nchains]) without updating the
+ * proposal state. */
+int smcmc_force_step(smcmc_engine* h, const double* point, int broadcast);
+
+/* ---- adaptation --------------------------------------------------------- */
+/* Pooled covariance exchange, POOLED mode.  reduce: sum the per-wavefront moment
+ * accumulators into the packed device vector M[(dim+1)(dim+2)/2] (row i <= dim,
+ * col j <= i, row `dim` holding sum(y) and the point count) and clear them.
+ * export/import copy M to/from a caller-owned DEVICE buffer so the caller can
+ * all-reduce it over ranks (RCCL).  apply: running centre/covariance update fed
+ * with the batch (TSimpleMCMC.H:1780-1820) and UpdateProposal (:1009-1390).
+ * smcmc_sync = reduce + apply, the single-GPU form. */
+int smcmc_reduce_moments(smcmc_engine* h);
+int smcmc_moments_size(const smcmc_engine* h);
+int smcmc_export_moments(smcmc_engine* h, double* dst_device);
+int smcmc_import_moments(smcmc_engine* h, const double* src_device);
+int smcmc_apply_moments(smcmc_engine* h);
+int smcmc_sync(smcmc_engine* h);
+int smcmc_update_proposal(smcmc_engine* h);   /* UpdateProposal() :1009 on the shared proposal */
+int smcmc_reset_proposal(smcmc_engine* h);    /* ResetProposal()  :1396 */
+
+/* ---- read back ---------------------------------------------------------- */
+int smcmc_nchains_padded(const smcmc_engine* h);          /* nchains rounded up to 64 */
+int smcmc_dim_padded(const smcmc_engine* h);              /* rows of the device state: the kernel family's register-array size */
+int smcmc_read_state(smcmc_engine* h, double* x, double* logl);   /* GetAccepted :502, x[dim][nchains] */
+int smcmc_read_lane_f64(smcmc_engine* h, int field, double* out);
+int smcmc_read_lane_i32(smcmc_engine* h, int field, int32_t* out);
+int smcmc_read_moments(smcmc_engine* h, double* out);     /* host copy of M */
+int smcmc_get_center(smcmc_engine* h, double* out);       /* GetEstimatedCenter :732 */
+int smcmc_set_center(smcmc_engine* h, const double* in);  /* SetEstimatedCenter :733 */
+int smcmc_get_covariance(smcmc_engine* h, double* out);   /* fCurrentCov, dim*dim */
+int smcmc_set_covariance(smcmc_engine* h, const double* in);
+int smcmc_get_decomposition(smcmc_engine* h, double* out);/* fDecomposition, dim*dim */
+/* device pointers for zero-copy consumers (x: [dim_padded][nchains_padded], logl: [nchains_padded]) */
+int smcmc_state_device_ptr(smcmc_engine* h, double** x, double** logl);
+
+/* ---- self test (no engine needed) --------------------------------------- */
+/* Runs every function of include/smcmc_detmath.h on the device for n inputs so
+ * tests can compare device and host bit for bit.  kind: 0 log, 1 exp,
+ * 2 sin(2 pi x), 3 cos(2 pi x), 4 pow_small(x, y), 5 sqrt, 6 x / y. */
+int smcmc_selftest_detmath(int device, int kind, int n, const double* x, const double* y, double* out);
+/* One v_mfma_f64_16x16x4_f64 chain: c[16][16] = sum_k a[16][k] b[k][16] over K
+ * (multiple of 4), the accumulation order the pooled moments rely on. */
+int smcmc_selftest_mfma(int device, int K, const double* a, const double* b, double* c);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

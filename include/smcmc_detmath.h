@@ -45,6 +45,12 @@
 
 #define SMCMC_FMA(a, b, c) __builtin_fma((a), (b), (c))
 
+#if defined(__clang__)
+#define SMCMC_UNROLL _Pragma("unroll")
+#else
+#define SMCMC_UNROLL
+#endif
+
 /* ---- bit casts -------------------------------------------------------- */
 SMCMC_HD uint64_t smcmc_d2u(double x) {
     union { double d; uint64_t u; } v; v.d = x; return v.u;
@@ -64,6 +70,7 @@ typedef struct { uint32_t v[4]; } smcmc_u32x4;
 
 SMCMC_HD smcmc_u32x4 smcmc_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2,
                                          uint32_t c3, uint32_t k0, uint32_t k1) {
+    SMCMC_UNROLL
     for (int r = 0; r < 10; ++r) {
         uint64_t p0 = (uint64_t)SMCMC_PHILOX_M0 * (uint64_t)c0;
         uint64_t p1 = (uint64_t)SMCMC_PHILOX_M1 * (uint64_t)c2;
@@ -98,7 +105,8 @@ SMCMC_HD double smcmc_u01(uint32_t w) {
 /* ---- log(x), x > 0 finite normal or subnormal ---------------------------
  * fdlibm e_log.c scheme: x = 2^k (1+f), sqrt(2)/2 < 1+f < sqrt(2),
  * s = f/(2+f), log(1+f) = f - hfsq + s (hfsq + R(s^2)).  < 1 ulp. */
-SMCMC_HD double smcmc_log(double x) {
+/* Core for finite normal x > 0 (no special cases, no branches). */
+SMCMC_HD double smcmc_log_pos(double x) {
     const double ln2_hi = 6.93147180369123816490e-01;
     const double ln2_lo = 1.90821492927058770002e-10;
     const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01,
@@ -106,17 +114,10 @@ SMCMC_HD double smcmc_log(double x) {
                  Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
                  Lg7 = 1.479819860511658591e-01;
     uint64_t ix = smcmc_d2u(x);
-    int k = 0;
-    if (x == 0.0) return -__builtin_inf();
-    if ((int64_t)ix < 0) return __builtin_nan("");
-    if ((ix >> 52) == 0x7FFu) return x;           /* +inf, nan */
-    if ((ix >> 52) == 0) {                        /* subnormal: scale by 2^54 */
-        x *= 18014398509481984.0; ix = smcmc_d2u(x); k = -54;
-    }
     uint32_t hx = (uint32_t)(ix >> 32);
     /* move the split point to sqrt(2)/2: add 0x3ff00000 - 0x3fe6a09e */
     hx += 0x3ff00000u - 0x3fe6a09eu;
-    k += (int)(hx >> 20) - 0x3ff;
+    int k = (int)(hx >> 20) - 0x3ff;
     hx = (hx & 0x000fffffu) + 0x3fe6a09eu;
     ix = ((uint64_t)hx << 32) | (ix & 0xffffffffull);
     double f = smcmc_u2d(ix) - 1.0;
@@ -129,6 +130,17 @@ SMCMC_HD double smcmc_log(double x) {
     double R = t2 + t1;
     double dk = (double)k;
     return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
+}
+
+SMCMC_HD double smcmc_log(double x) {
+    uint64_t ix = smcmc_d2u(x);
+    if (x == 0.0) return -__builtin_inf();
+    if ((int64_t)ix < 0) return __builtin_nan("");
+    if ((ix >> 52) == 0x7FFu) return x;           /* +inf, nan */
+    if ((ix >> 52) == 0) {                        /* subnormal: scale by 2^54 */
+        return smcmc_log_pos(x * 18014398509481984.0) - 54.0 * 6.93147180559945286227e-01;
+    }
+    return smcmc_log_pos(x);
 }
 
 /* ---- exp(x), |x| < 700 (fdlibm e_exp.c scheme) --------------------------- */
@@ -162,11 +174,31 @@ SMCMC_HD double smcmc_exp(double x) {
     return (y * smcmc_u2d((uint64_t)(0x3ff + (k + 1000)) << 52)) * 9.33263618503218878990e-302;     /* 2^-1000 */
 }
 
-/* pow(x, y) for x > 0 and small |y| (the sigma update uses y <= 1/500,
- * TSimpleMCMC.H:1772-1775).  exp(y*log x): with |y log x| << 1 the result is
- * within ~1 ulp of the true power. */
+/* exp(x) for |x| <= 700 without the overflow/underflow branches. */
+SMCMC_HD double smcmc_exp_mid(double x) {
+    const double ln2HI = 6.93147180369123816490e-01;
+    const double ln2LO = 1.90821492927058770002e-10;
+    const double invln2 = 1.44269504088896338700e+00;
+    const double P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03,
+                 P3 = 6.61375632143793436117e-05, P4 = -1.65339022054652515390e-06,
+                 P5 = 4.13813679705723846039e-08;
+    double kf = invln2 * x;
+    kf = (kf + 6755399441055744.0) - 6755399441055744.0;
+    int k = (int)kf;
+    double hi = x - kf * ln2HI;
+    double lo = kf * ln2LO;
+    double r = hi - lo;
+    double t = r * r;
+    double c = r - t * SMCMC_FMA(t, SMCMC_FMA(t, SMCMC_FMA(t, SMCMC_FMA(t, P5, P4), P3), P2), P1);
+    double y = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi);
+    return y * smcmc_u2d((uint64_t)(0x3ff + k) << 52);
+}
+
+/* pow(x, y) for finite normal x > 0 and small |y| (the sigma update uses
+ * y <= 1/500, TSimpleMCMC.H:1772-1775).  exp(y*log x): with |y log x| << 1 the
+ * result is within ~1 ulp of the true power. */
 SMCMC_HD double smcmc_pow_small(double x, double y) {
-    return smcmc_exp(y * smcmc_log(x));
+    return smcmc_exp_mid(y * smcmc_log_pos(x));
 }
 
 /* ---- sin/cos(2*pi*u), u in [0,1) ----------------------------------------
@@ -192,12 +224,12 @@ SMCMC_HD void smcmc_sincos2pi(double u, double* sn, double* cs) {
     double pc = SMCMC_FMA(z, SMCMC_FMA(z, SMCMC_FMA(z, SMCMC_FMA(z, SMCMC_FMA(z, C6, C5), C4), C3), C2), C1);
     double hz = 0.5 * z;
     double c = (1.0 - hz) + (z * z) * pc;
-    switch (j & 3) {
-        case 0:  *sn = s;  *cs = c;  break;
-        case 1:  *sn = c;  *cs = -s; break;
-        case 2:  *sn = -s; *cs = -c; break;
-        default: *sn = -c; *cs = s;  break;
-    }
+    /* quadrant rotation: q=0 (s,c)  q=1 (c,-s)  q=2 (-s,-c)  q=3 (-c,s) */
+    const int swap = j & 1;
+    double rs = swap ? c : s;
+    double rc = swap ? s : c;
+    *sn = (j & 2) ? -rs : rs;
+    *cs = ((j + 1) & 2) ? -rc : rc;
 }
 
 /* ---- Box-Muller pair from two 32-bit words -------------------------------
@@ -205,11 +237,16 @@ SMCMC_HD void smcmc_sincos2pi(double u, double* sn, double* cs) {
 SMCMC_HD void smcmc_normal_pair(uint32_t w0, uint32_t w1, double* n0, double* n1) {
     double u1 = smcmc_u01(w0);
     double u2 = smcmc_u01(w1);
-    double r = __builtin_sqrt(-2.0 * smcmc_log(u1));
+    double r = __builtin_sqrt(-2.0 * smcmc_log_pos(u1));
     double sn, cs;
     smcmc_sincos2pi(u2, &sn, &cs);
     *n0 = r * cs;
     *n1 = r * sn;
+}
+
+/* v[i] for a run-time i without indexing memory. */
+SMCMC_HD uint32_t smcmc_select_word(smcmc_u32x4 b, uint32_t i) {
+    return (i == 0u) ? b.v[0] : (i == 1u) ? b.v[1] : (i == 2u) ? b.v[2] : b.v[3];
 }
 
 /* Word index of the Metropolis uniform for dimension D (see header comment). */

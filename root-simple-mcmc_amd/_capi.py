@@ -1,0 +1,101 @@
+"""ctypes binding of the C ABI declared in include/smcmc.h.
+
+This is the reference-side stub a Python caller needs; the C++ counterpart is
+include/TSimpleMCMC_amd.H.  Loading fails loudly when the in-tree library is
+missing: there is no CPU fallback behind this package.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libsmcmc_amd.so")
+
+OK, ERR_INVALID, ERR_LOGIC, ERR_RUNTIME, ERR_BAD_START, ERR_UNSUPPORTED, ERR_HIP, ERR_NO_DEVICE = range(8)
+
+LIKE_ISO_GAUSS, LIKE_QUADFORM, LIKE_ROSENBROCK = 0, 1, 2
+MODE_FROZEN, MODE_POOLED = 0, 1
+
+PARAMS = ["COVARIANCE_WINDOW", "COVARIANCE_DEWEIGHT", "ACCEPTANCE_WINDOW", "ACCEPTANCE_DEWEIGHT",
+          "ACCEPTANCE_RIGIDITY", "TARGET_ACCEPTANCE", "SIGMA", "MAXIMUM_CORRELATION", "STEP_RMS_WINDOW",
+          "NEXT_UPDATE", "COVARIANCE_TRIALS", "CENTER_TRIALS", "COVARIANCE_TRACE", "TOTAL_STEPS",
+          "SIGMA_TRACE", "UPDATE_COUNT", "LAST_UPDATE_PATH", "EXACT_ARITHMETIC"]
+P = {name: i for i, name in enumerate(PARAMS)}
+LANE_F64 = {name: i for i, name in enumerate(
+    ["logl", "sigma", "acceptance", "acceptance_trials", "rigidity", "last_value", "last_x0", "step_rms",
+     "logl_proposed"])}
+LANE_I32 = {name: i for i, name in enumerate(
+    ["trials", "successes", "next_update", "naccept", "step_rms_trials", "last_accept"])}
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+_H = C.c_void_p
+
+# every symbol include/smcmc.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "smcmc_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint32, C.c_int, C.POINTER(_H)]),
+    "smcmc_destroy": (C.c_int, [_H]),
+    "smcmc_last_error": (C.c_char_p, [_H]),
+    "smcmc_status_string": (C.c_char_p, [C.c_int]),
+    "smcmc_version": (C.c_int, []),
+    "smcmc_max_register_dim": (C.c_int, []),
+    "smcmc_set_stream": (C.c_int, [_H, C.c_void_p]),
+    "smcmc_set_likelihood_params": (C.c_int, [_H, _dp, C.c_int]),
+    "smcmc_set_mode": (C.c_int, [_H, C.c_int]),
+    "smcmc_set_gaussian": (C.c_int, [_H, C.c_int, C.c_double]),
+    "smcmc_set_uniform": (C.c_int, [_H, C.c_int, C.c_double, C.c_double]),
+    "smcmc_set_correlation": (C.c_int, [_H, C.c_int, C.c_int, C.c_double]),
+    "smcmc_reset_correlations": (C.c_int, [_H]),
+    "smcmc_set_param": (C.c_int, [_H, C.c_int, C.c_double]),
+    "smcmc_get_param": (C.c_int, [_H, C.c_int, _dp]),
+    "smcmc_start": (C.c_int, [_H, _dp, C.c_int]),
+    "smcmc_step": (C.c_int, [_H, C.c_int, C.c_int]),
+    "smcmc_step_save": (C.c_int, [_H, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "smcmc_force_step": (C.c_int, [_H, _dp, C.c_int]),
+    "smcmc_reduce_moments": (C.c_int, [_H]),
+    "smcmc_moments_size": (C.c_int, [_H]),
+    "smcmc_export_moments": (C.c_int, [_H, C.c_void_p]),
+    "smcmc_import_moments": (C.c_int, [_H, C.c_void_p]),
+    "smcmc_apply_moments": (C.c_int, [_H]),
+    "smcmc_sync": (C.c_int, [_H]),
+    "smcmc_update_proposal": (C.c_int, [_H]),
+    "smcmc_reset_proposal": (C.c_int, [_H]),
+    "smcmc_nchains_padded": (C.c_int, [_H]),
+    "smcmc_dim_padded": (C.c_int, [_H]),
+    "smcmc_read_state": (C.c_int, [_H, _dp, _dp]),
+    "smcmc_read_lane_f64": (C.c_int, [_H, C.c_int, _dp]),
+    "smcmc_read_lane_i32": (C.c_int, [_H, C.c_int, _ip]),
+    "smcmc_read_moments": (C.c_int, [_H, _dp]),
+    "smcmc_get_center": (C.c_int, [_H, _dp]),
+    "smcmc_set_center": (C.c_int, [_H, _dp]),
+    "smcmc_get_covariance": (C.c_int, [_H, _dp]),
+    "smcmc_set_covariance": (C.c_int, [_H, _dp]),
+    "smcmc_get_decomposition": (C.c_int, [_H, _dp]),
+    "smcmc_state_device_ptr": (C.c_int, [_H, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "smcmc_selftest_detmath": (C.c_int, [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp]),
+    "smcmc_selftest_mfma": (C.c_int, [C.c_int, C.c_int, _dp, _dp, _dp]),
+}
+
+_lib = None
+
+
+class SmcmcError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(f"smcmc status {status}: {message}")
+        self.status = status
+
+
+def load():
+    """Load the in-tree HIP library.  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python root-simple-mcmc_amd/build.py` "
+                "(or __graft_entry__.build()).  There is no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)   # AttributeError if the library lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib

@@ -1,0 +1,688 @@
+// smcmc_engine.hip -- host engine behind the C ABI of include/smcmc.h.
+//
+// Owns the device buffers ([dim][chain] state, per-chain scalar columns, the
+// per-wavefront moment tiles), the shared proposal (smcmc_proposal.hpp) and the
+// launch logic.  There is no CPU execution path: every entry point that needs
+// the device fails with SMCMC_ERR_NO_DEVICE / SMCMC_ERR_HIP when it is missing.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "smcmc.h"
+#include "smcmc_kernels.hip.h"
+#include "smcmc_proposal.hpp"
+
+using namespace smcmc;
+
+namespace {
+
+// register-resident kernel families, smallest first (SMCMC_FOR_EACH_DP)
+#define SMCMC_DP_ENTRY(n) n,
+constexpr int kDPList[] = {SMCMC_FOR_EACH_DP(SMCMC_DP_ENTRY)};
+#undef SMCMC_DP_ENTRY
+constexpr int kNumDP = sizeof(kDPList) / sizeof(kDPList[0]);
+
+int pick_dp(int dim) {
+    for (int i = 0; i < kNumDP; ++i)
+        if (dim <= kDPList[i]) return kDPList[i];
+    return -1;
+}
+
+hipError_t dispatch_step(int dp, const StepParams& p, int like, bool exact, bool fullu, bool moments,
+                         hipStream_t s) {
+    switch (dp) {
+#define SMCMC_DP_CASE(n) case n: return launch_step<n>(p, like, exact, fullu, moments, s);
+        SMCMC_FOR_EACH_DP(SMCMC_DP_CASE)
+#undef SMCMC_DP_CASE
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t dispatch_reduce(int dp, double* gacc, int ngroups, int D, double* moments, hipStream_t s) {
+    switch (dp) {
+#define SMCMC_DP_CASE(n) case n: return launch_reduce<n>(gacc, ngroups, D, moments, s);
+        SMCMC_FOR_EACH_DP(SMCMC_DP_CASE)
+#undef SMCMC_DP_CASE
+        default: return hipErrorInvalidValue;
+    }
+}
+
+int tiles_for(int dp) {
+    const int t = (dp + 1 + 15) / 16;
+    return t * (t + 1) / 2;
+}
+
+}  // namespace
+
+struct smcmc_engine {
+    int dim = 0, nchains = 0, npad = 0, ngroups = 0, dp = 0, nt = 0;
+    int likelihood = 0, mode = SMCMC_MODE_POOLED, device = 0;
+    bool exact = true, started = false;
+    uint64_t seed = 0;
+    uint32_t chain_offset = 0;
+    uint32_t total_steps = 0;
+    int step_rms_window = 1000;
+    hipStream_t stream = nullptr;
+    SharedProposal* prop = nullptr;
+    std::vector<double> like_params;
+    // pending per-chain adjustments from the last pooled UpdateProposal
+    double pending_sigma_scale = 1.0;
+    int pending_deweight = 0;
+    bool has_forced = false;
+    // device
+    double* d_x = nullptr;
+    double* d_lane_f64 = nullptr;
+    int32_t* d_lane_i32 = nullptr;
+    double* d_U = nullptr;
+    double* d_like = nullptr;
+    double* d_c0 = nullptr;
+    double* d_gacc = nullptr;
+    double* d_moments = nullptr;
+    double* d_forced = nullptr;
+    std::string error;
+};
+
+namespace {
+
+int fail(smcmc_engine* h, int status, const std::string& msg) {
+    if (h) h->error = msg;
+    return status;
+}
+
+#define HIP_TRY(h, expr)                                                                   \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess)                                                              \
+            return fail((h), SMCMC_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+int status_of(smcmc_engine* h, UpdateStatus st) {
+    switch (st) {
+        case UpdateStatus::Ok: return SMCMC_OK;
+        case UpdateStatus::InvalidTrace: return fail(h, SMCMC_ERR_RUNTIME, "Invalid trace");
+        case UpdateStatus::IllegalProposalType: return fail(h, SMCMC_ERR_INVALID, "Illegal proposal type");
+        case UpdateStatus::UserCorrelationsFailed:
+            return fail(h, SMCMC_ERR_RUNTIME, "Decomposition of user correlations failed");
+        case UpdateStatus::TargetNotSet: return fail(h, SMCMC_ERR_RUNTIME, "Target acceptance not initialized");
+    }
+    return SMCMC_ERR_RUNTIME;
+}
+
+size_t npacked(const smcmc_engine* h) { return (size_t)(h->dim + 1) * (h->dim + 2) / 2; }
+
+// decomposition (and, for QUADFORM, the Error matrix) zero-padded to [dp][dp]
+int upload_padded(smcmc_engine* h, const double* src, double* dst_dev) {
+    const int D = h->dim, DP = h->dp;
+    std::vector<double> pad((size_t)DP * DP, 0.0);
+    for (int i = 0; i < D; ++i)
+        for (int j = 0; j < D; ++j) pad[(size_t)i * DP + j] = src[(size_t)i * D + j];
+    HIP_TRY(h, hipMemcpyAsync(dst_dev, pad.data(), pad.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SMCMC_OK;
+}
+
+int upload_shared(smcmc_engine* h) {
+    int st = upload_padded(h, h->prop->decomp.data(), h->d_U);
+    if (st) return st;
+    std::vector<double> c0(h->dp, 0.0);
+    for (int d = 0; d < h->dim; ++d) c0[d] = h->prop->centre[d];
+    HIP_TRY(h, hipMemcpyAsync(h->d_c0, c0.data(), c0.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SMCMC_OK;
+}
+
+int upload_like(smcmc_engine* h) {
+    if (h->likelihood == SMCMC_LIKE_QUADFORM) {
+        if ((int)h->like_params.size() != h->dim * h->dim)
+            return fail(h, SMCMC_ERR_INVALID, "QUADFORM needs dim*dim likelihood parameters (the Error matrix)");
+        // the kernel walks Error(j,i) with j innermost (TDummyLogLikelihood.H:24-28): hand it
+        // the transpose so that walk is contiguous
+        const int D = h->dim;
+        std::vector<double> et((size_t)D * D);
+        for (int i = 0; i < D; ++i)
+            for (int j = 0; j < D; ++j) et[(size_t)i * D + j] = h->like_params[(size_t)j * D + i];
+        return upload_padded(h, et.data(), h->d_like);
+    }
+    double b = 100.0;   // ROSEN_B, THardLogLikelihood.H:53
+    if (h->likelihood == SMCMC_LIKE_ROSENBROCK && !h->like_params.empty()) b = h->like_params[0];
+    HIP_TRY(h, hipMemcpyAsync(h->d_like, &b, sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SMCMC_OK;
+}
+
+StepParams make_params(smcmc_engine* h, int nsteps, int metropolis) {
+    const SharedProposal& P = *h->prop;
+    StepParams p;
+    std::memset(&p, 0, sizeof(p));
+    p.nchains = h->nchains; p.npad = h->npad; p.dim = h->dim;
+    p.nsteps = nsteps; p.metropolis = metropolis;
+    p.step0 = h->total_steps;
+    p.chain_offset = h->chain_offset;
+    p.seed = h->seed;
+    p.U = h->d_U; p.like = h->d_like; p.c0 = h->d_c0;
+    p.target = P.target;
+    p.acc_window = P.acceptanceWindow;
+    double asig = P.target * (1.0 - P.target);              // TSimpleMCMC.H:1746-1747
+    asig = std::sqrt(asig / P.acceptanceWindow);
+    p.asig = asig;
+    p.max_up = (double)h->dim * (double)h->dim;             // :1050
+    if (P.acceptanceDeweight > 0.0) {
+        const double w = 1.0 - std::min(P.acceptanceDeweight, 1.0);
+        p.acc_w = w;
+        p.acc_wW = w * P.acceptanceWindow;
+    } else {
+        p.acc_w = -1.0;
+        p.acc_wW = 0.0;
+    }
+    p.pending_sigma_scale = h->pending_sigma_scale;
+    p.pending_deweight = h->pending_deweight;
+    p.per_lane_update = (h->mode == SMCMC_MODE_FROZEN) ? 1 : 0;
+    p.step_rms_window = h->step_rms_window;
+    p.has_forced = h->has_forced ? 1 : 0;
+    p.forced = h->d_forced;
+    p.x = h->d_x; p.lane_f64 = h->d_lane_f64; p.lane_i32 = h->d_lane_i32;
+    p.gacc = h->d_gacc;
+    p.save_x = nullptr; p.save_logl = nullptr; p.save_stride = 1;
+    return p;
+}
+
+int launch(smcmc_engine* h, int nsteps, int metropolis, int stride, double* save_x, double* save_logl) {
+    if (!h) return SMCMC_ERR_INVALID;
+    if (!h->started) return fail(h, SMCMC_ERR_INVALID, "Uninitialized starting point");   // TSimpleMCMC.H:371-374
+    if (nsteps <= 0) return SMCMC_OK;
+    if (metropolis < 0 || metropolis > 2) return fail(h, SMCMC_ERR_INVALID, "metropolis must be 0, 1 or 2");
+    StepParams p = make_params(h, nsteps, metropolis);
+    if (save_x) {
+        if (stride <= 0) return fail(h, SMCMC_ERR_INVALID, "save stride must be positive");
+        p.save_x = save_x; p.save_logl = save_logl; p.save_stride = stride;
+    }
+    const bool moments = (h->mode == SMCMC_MODE_POOLED);
+    const bool fullu = h->prop->decompFull;
+    const bool exact = h->exact || fullu;   // the full (eigen) decomposition only exists in reference order
+    hipError_t e = dispatch_step(h->dp, p, h->likelihood, exact, fullu, moments, h->stream);
+    if (e != hipSuccess) return fail(h, SMCMC_ERR_HIP, std::string("step kernel launch: ") + hipGetErrorString(e));
+    h->total_steps += (uint32_t)nsteps;
+    h->pending_sigma_scale = 1.0;
+    h->pending_deweight = 0;
+    h->has_forced = false;
+    return SMCMC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int smcmc_version(void) { return 100; }
+int smcmc_max_register_dim(void) { return kDPList[kNumDP - 1]; }
+
+const char* smcmc_status_string(int status) {
+    switch (status) {
+        case SMCMC_OK: return "ok";
+        case SMCMC_ERR_INVALID: return "invalid argument";
+        case SMCMC_ERR_LOGIC: return "logic error";
+        case SMCMC_ERR_RUNTIME: return "runtime error";
+        case SMCMC_ERR_BAD_START: return "bad starting point";
+        case SMCMC_ERR_UNSUPPORTED: return "unsupported on the HIP path";
+        case SMCMC_ERR_HIP: return "HIP runtime error";
+        case SMCMC_ERR_NO_DEVICE: return "no HIP device";
+        default: return "unknown status";
+    }
+}
+
+const char* smcmc_last_error(const smcmc_engine* h) { return h ? h->error.c_str() : "null engine"; }
+
+int smcmc_create(int dim, int nchains, int likelihood, uint64_t seed, uint32_t chain_offset, int device,
+                 smcmc_engine** out) {
+    if (!out) return SMCMC_ERR_INVALID;
+    *out = nullptr;
+    if (dim < 1 || nchains < 1) return SMCMC_ERR_INVALID;
+    if (likelihood < SMCMC_LIKE_ISO_GAUSS || likelihood > SMCMC_LIKE_ROSENBROCK) return SMCMC_ERR_INVALID;
+    if (likelihood == SMCMC_LIKE_ROSENBROCK && dim < 2) return SMCMC_ERR_INVALID;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return SMCMC_ERR_NO_DEVICE;
+    if (device < 0 || device >= ndev) return SMCMC_ERR_NO_DEVICE;
+    const int dp = pick_dp(dim);
+    if (dp < 0) return SMCMC_ERR_UNSUPPORTED;
+    smcmc_engine* h = new (std::nothrow) smcmc_engine();
+    if (!h) return SMCMC_ERR_RUNTIME;
+    h->dim = dim; h->nchains = nchains; h->likelihood = likelihood; h->seed = seed;
+    h->chain_offset = chain_offset; h->device = device; h->dp = dp;
+    h->npad = (nchains + kWave - 1) / kWave * kWave;
+    h->ngroups = h->npad / kWave;
+    h->nt = tiles_for(dp);
+    h->prop = new SharedProposal(dim);
+    *out = h;
+    HIP_TRY(h, hipSetDevice(device));
+    const size_t np = (size_t)h->npad;
+    HIP_TRY(h, hipMalloc(&h->d_x, sizeof(double) * np * dp));        // rows >= dim stay zero
+    HIP_TRY(h, hipMalloc(&h->d_forced, sizeof(double) * np * dp));
+    HIP_TRY(h, hipMalloc(&h->d_lane_f64, sizeof(double) * np * SMCMC_LANE_F64_COUNT_));
+    HIP_TRY(h, hipMalloc(&h->d_lane_i32, sizeof(int32_t) * np * SMCMC_LANE_I32_COUNT_));
+    HIP_TRY(h, hipMalloc(&h->d_U, sizeof(double) * dp * dp));
+    HIP_TRY(h, hipMalloc(&h->d_like, sizeof(double) * dp * dp));
+    HIP_TRY(h, hipMalloc(&h->d_c0, sizeof(double) * dp));
+    HIP_TRY(h, hipMalloc(&h->d_gacc, sizeof(double) * (size_t)h->ngroups * h->nt * 4 * kWave));
+    HIP_TRY(h, hipMalloc(&h->d_moments, sizeof(double) * npacked(h)));
+    HIP_TRY(h, hipMemset(h->d_x, 0, sizeof(double) * np * dp));
+    HIP_TRY(h, hipMemset(h->d_forced, 0, sizeof(double) * np * dp));
+    HIP_TRY(h, hipMemset(h->d_lane_f64, 0, sizeof(double) * np * SMCMC_LANE_F64_COUNT_));
+    HIP_TRY(h, hipMemset(h->d_lane_i32, 0, sizeof(int32_t) * np * SMCMC_LANE_I32_COUNT_));
+    HIP_TRY(h, hipMemset(h->d_U, 0, sizeof(double) * dp * dp));
+    HIP_TRY(h, hipMemset(h->d_like, 0, sizeof(double) * dp * dp));
+    HIP_TRY(h, hipMemset(h->d_c0, 0, sizeof(double) * dp));
+    HIP_TRY(h, hipMemset(h->d_gacc, 0, sizeof(double) * (size_t)h->ngroups * h->nt * 4 * kWave));
+    HIP_TRY(h, hipMemset(h->d_moments, 0, sizeof(double) * npacked(h)));
+    return SMCMC_OK;
+}
+
+int smcmc_destroy(smcmc_engine* h) {
+    if (!h) return SMCMC_OK;
+    if (h->d_x) {
+        (void)hipSetDevice(h->device);
+        (void)hipStreamSynchronize(h->stream);
+    }
+    (void)hipFree(h->d_x); (void)hipFree(h->d_forced); (void)hipFree(h->d_lane_f64); (void)hipFree(h->d_lane_i32);
+    (void)hipFree(h->d_U); (void)hipFree(h->d_like); (void)hipFree(h->d_c0); (void)hipFree(h->d_gacc);
+    (void)hipFree(h->d_moments);
+    delete h->prop;
+    delete h;
+    return SMCMC_OK;
+}
+
+int smcmc_set_stream(smcmc_engine* h, void* hip_stream) {
+    if (!h) return SMCMC_ERR_INVALID;
+    h->stream = (hipStream_t)hip_stream;
+    return SMCMC_OK;
+}
+
+int smcmc_set_likelihood_params(smcmc_engine* h, const double* params, int count) {
+    if (!h || count < 0 || (count > 0 && !params)) return SMCMC_ERR_INVALID;
+    h->like_params.assign(params, params + count);
+    if (h->started) return upload_like(h);
+    return SMCMC_OK;
+}
+
+int smcmc_set_mode(smcmc_engine* h, int mode) {
+    if (!h || (mode != SMCMC_MODE_FROZEN && mode != SMCMC_MODE_POOLED)) return SMCMC_ERR_INVALID;
+    h->mode = mode;
+    h->prop->covFrozen = (mode == SMCMC_MODE_FROZEN);
+    return SMCMC_OK;
+}
+
+int smcmc_set_gaussian(smcmc_engine* h, int dim, double sigma) {
+    if (!h) return SMCMC_ERR_INVALID;
+    if (dim < 0 || dim >= h->dim) return fail(h, SMCMC_ERR_INVALID, "Dimension is out of range.");   // :856-860
+    h->prop->ptype[dim] = 0;
+    h->prop->param1[dim] = sigma * sigma;
+    return SMCMC_OK;
+}
+
+int smcmc_set_uniform(smcmc_engine* h, int dim, double minimum, double maximum) {
+    if (!h) return SMCMC_ERR_INVALID;
+    if (dim < 0 || dim >= h->dim) return fail(h, SMCMC_ERR_INVALID, "Dimension is out of range.");
+    (void)minimum; (void)maximum;
+    return fail(h, SMCMC_ERR_UNSUPPORTED, "uniform per-dimension proposals are not on the HIP path yet");
+}
+
+int smcmc_set_correlation(smcmc_engine* h, int d1, int d2, double c) {
+    if (!h) return SMCMC_ERR_INVALID;
+    if (d1 < 0 || d2 < 0 || d1 >= h->dim || d2 >= h->dim) return fail(h, SMCMC_ERR_INVALID, "Dimension is out of range.");
+    if (d1 == d2) return fail(h, SMCMC_ERR_INVALID, "Dimensions must be different for correlations");   // :884-890
+    const double mc = h->prop->maxCorrelation;
+    if (c < -mc) c = -mc;                                                                            // :891-902
+    if (c > mc) c = mc;
+    h->prop->correlations.push_back({d1, d2, c});
+    return SMCMC_OK;
+}
+
+int smcmc_reset_correlations(smcmc_engine* h) {
+    if (!h) return SMCMC_ERR_INVALID;
+    h->prop->correlations.clear();
+    return SMCMC_OK;
+}
+
+static int broadcast_lane_f64(smcmc_engine* h, int field, double v) {
+    std::vector<double> col(h->npad, 0.0);
+    for (int c = 0; c < h->nchains; ++c) col[c] = v;
+    HIP_TRY(h, hipMemcpyAsync(h->d_lane_f64 + (size_t)field * h->npad, col.data(), col.size() * sizeof(double),
+                              hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SMCMC_OK;
+}
+
+static int broadcast_lane_i32(smcmc_engine* h, int field, int32_t v) {
+    std::vector<int32_t> col(h->npad, 0);
+    for (int c = 0; c < h->nchains; ++c) col[c] = v;
+    HIP_TRY(h, hipMemcpyAsync(h->d_lane_i32 + (size_t)field * h->npad, col.data(), col.size() * sizeof(int32_t),
+                              hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SMCMC_OK;
+}
+
+int smcmc_set_param(smcmc_engine* h, int which, double v) {
+    if (!h) return SMCMC_ERR_INVALID;
+    SharedProposal& P = *h->prop;
+    switch (which) {
+        case SMCMC_P_COVARIANCE_WINDOW: P.covWindow = v; return SMCMC_OK;
+        case SMCMC_P_COVARIANCE_DEWEIGHT: P.covDeweight = v; return SMCMC_OK;
+        case SMCMC_P_ACCEPTANCE_WINDOW: P.acceptanceWindow = v; return SMCMC_OK;
+        case SMCMC_P_ACCEPTANCE_DEWEIGHT: P.acceptanceDeweight = v; return SMCMC_OK;
+        case SMCMC_P_ACCEPTANCE_RIGIDITY:
+            P.rigidity = v;
+            return h->started ? broadcast_lane_f64(h, SMCMC_LANE_RIGIDITY, v) : SMCMC_OK;
+        case SMCMC_P_TARGET_ACCEPTANCE: P.target = v; return SMCMC_OK;
+        case SMCMC_P_SIGMA:
+            P.sigma = v;
+            return h->started ? broadcast_lane_f64(h, SMCMC_LANE_SIGMA, v) : SMCMC_OK;
+        case SMCMC_P_MAXIMUM_CORRELATION: P.maxCorrelation = v; return SMCMC_OK;
+        case SMCMC_P_STEP_RMS_WINDOW: h->step_rms_window = (int)v; return SMCMC_OK;
+        case SMCMC_P_NEXT_UPDATE:
+            P.nextUpdate = (int)v;
+            return h->started ? broadcast_lane_i32(h, SMCMC_LANE_NEXT_UPDATE, (int32_t)v) : SMCMC_OK;
+        case SMCMC_P_COVARIANCE_TRIALS: P.covTrials = v; return SMCMC_OK;
+        case SMCMC_P_CENTER_TRIALS: P.centreTrials = v; return SMCMC_OK;
+        case SMCMC_P_EXACT_ARITHMETIC: h->exact = (v != 0.0); return SMCMC_OK;
+        default: return fail(h, SMCMC_ERR_INVALID, "parameter is read only or unknown");
+    }
+}
+
+int smcmc_get_param(smcmc_engine* h, int which, double* out) {
+    if (!h || !out) return SMCMC_ERR_INVALID;
+    const SharedProposal& P = *h->prop;
+    switch (which) {
+        case SMCMC_P_COVARIANCE_WINDOW: *out = P.covWindow; break;
+        case SMCMC_P_COVARIANCE_DEWEIGHT: *out = P.covDeweight; break;
+        case SMCMC_P_ACCEPTANCE_WINDOW: *out = P.acceptanceWindow; break;
+        case SMCMC_P_ACCEPTANCE_DEWEIGHT: *out = P.acceptanceDeweight; break;
+        case SMCMC_P_ACCEPTANCE_RIGIDITY: *out = P.rigidity; break;
+        case SMCMC_P_TARGET_ACCEPTANCE: *out = P.target; break;
+        case SMCMC_P_SIGMA: {
+            if (!h->started) { *out = P.sigma; break; }
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+            HIP_TRY(h, hipMemcpy(out, h->d_lane_f64 + (size_t)SMCMC_LANE_SIGMA * h->npad, sizeof(double),
+                                 hipMemcpyDeviceToHost));
+            break;
+        }
+        case SMCMC_P_MAXIMUM_CORRELATION: *out = P.maxCorrelation; break;
+        case SMCMC_P_STEP_RMS_WINDOW: *out = h->step_rms_window; break;
+        case SMCMC_P_NEXT_UPDATE: *out = P.nextUpdate; break;
+        case SMCMC_P_COVARIANCE_TRIALS: *out = P.covTrials; break;
+        case SMCMC_P_CENTER_TRIALS: *out = P.centreTrials; break;
+        case SMCMC_P_COVARIANCE_TRACE: *out = P.trace(); break;
+        case SMCMC_P_TOTAL_STEPS: *out = h->total_steps; break;
+        case SMCMC_P_SIGMA_TRACE: *out = P.sigmaTrace; break;
+        case SMCMC_P_UPDATE_COUNT: *out = P.updateCount; break;
+        case SMCMC_P_LAST_UPDATE_PATH: *out = P.lastPath; break;
+        case SMCMC_P_EXACT_ARITHMETIC: *out = h->exact ? 1.0 : 0.0; break;
+        default: return fail(h, SMCMC_ERR_INVALID, "unknown parameter");
+    }
+    return SMCMC_OK;
+}
+
+int smcmc_start(smcmc_engine* h, const double* x0, int broadcast) {
+    if (!h || !x0) return SMCMC_ERR_INVALID;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const int D = h->dim, N = h->nchains;
+    const size_t NP = (size_t)h->npad;
+    int st = upload_like(h);
+    if (st) return st;
+    std::vector<double> x(NP * h->dp, 0.0);
+    for (int d = 0; d < D; ++d)
+        for (int c = 0; c < N; ++c) x[(size_t)d * NP + c] = broadcast ? x0[d] : x0[(size_t)d * N + c];
+    HIP_TRY(h, hipMemcpyAsync(h->d_x, x.data(), x.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+
+    // Start's likelihood call (TSimpleMCMC.H:258): a scan step (metropolis == 2) that is
+    // forced to the start point evaluates and stores logL(start) for every chain
+    // without touching the proposal state.
+    HIP_TRY(h, hipMemcpyAsync(h->d_forced, x.data(), x.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->d_lane_f64, 0, sizeof(double) * NP * SMCMC_LANE_F64_COUNT_, h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->d_lane_i32, 0, sizeof(int32_t) * NP * SMCMC_LANE_I32_COUNT_, h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->d_gacc, 0, sizeof(double) * (size_t)h->ngroups * h->nt * 4 * kWave, h->stream));
+    {
+        StepParams p;
+        std::memset(&p, 0, sizeof(p));
+        p.nchains = N; p.npad = h->npad; p.dim = D; p.nsteps = 1; p.metropolis = 2;
+        p.seed = h->seed; p.chain_offset = h->chain_offset;
+        p.U = h->d_U; p.like = h->d_like; p.c0 = h->d_c0;
+        p.target = 0.234; p.acc_window = 1.0; p.asig = 1.0; p.max_up = 1.0; p.acc_w = -1.0;
+        p.pending_sigma_scale = 1.0;
+        p.step_rms_window = 0;
+        p.has_forced = 1; p.forced = h->d_forced;
+        p.x = h->d_x; p.lane_f64 = h->d_lane_f64; p.lane_i32 = h->d_lane_i32; p.gacc = h->d_gacc;
+        p.save_stride = 1;
+        hipError_t e = dispatch_step(h->dp, p, h->likelihood, true, false, false, h->stream);
+        if (e != hipSuccess) return fail(h, SMCMC_ERR_HIP, std::string("start kernel launch: ") + hipGetErrorString(e));
+    }
+    std::vector<double> logl(NP, 0.0);
+    HIP_TRY(h, hipMemcpyAsync(logl.data(), h->d_lane_f64 + (size_t)SMCMC_LANE_LOGL * NP, NP * sizeof(double),
+                              hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    for (int c = 0; c < N; ++c)
+        if (!std::isfinite(logl[c]) || logl[c] < -0.999999E+10)                      // :265-268
+            return fail(h, SMCMC_ERR_BAD_START, "start likelihood is not finite or < -0.999999E+10");
+
+    // InitializeState on chain 0's start (TSimpleMCMC.H:272, 1679-1714)
+    std::vector<double> p0(D);
+    for (int d = 0; d < D; ++d) p0[d] = x[(size_t)d * NP];
+    SharedProposal& P = *h->prop;
+    P.covFrozen = (h->mode == SMCMC_MODE_FROZEN);
+    st = status_of(h, P.initialize(p0.data()));
+    if (st) return st;
+
+    std::vector<double> lf(NP * SMCMC_LANE_F64_COUNT_, 0.0);
+    std::vector<int32_t> li(NP * SMCMC_LANE_I32_COUNT_, 0);
+    for (int c = 0; c < N; ++c) {
+        lf[(size_t)SMCMC_LANE_LOGL * NP + c] = logl[c];
+        lf[(size_t)SMCMC_LANE_SIGMA * NP + c] = P.sigma;
+        lf[(size_t)SMCMC_LANE_ACCEPTANCE * NP + c] = P.acceptance;
+        lf[(size_t)SMCMC_LANE_ACCEPTANCE_TRIALS * NP + c] = P.acceptanceTrials;
+        lf[(size_t)SMCMC_LANE_RIGIDITY * NP + c] = P.rigidity;
+        lf[(size_t)SMCMC_LANE_LAST_VALUE * NP + c] = logl[c];
+        lf[(size_t)SMCMC_LANE_LAST_X0 * NP + c] = x[c];
+        lf[(size_t)SMCMC_LANE_LOGL_PROPOSED * NP + c] = logl[c];
+        li[(size_t)SMCMC_LANE_NEXT_UPDATE * NP + c] = P.nextUpdate;
+    }
+    HIP_TRY(h, hipMemcpyAsync(h->d_lane_f64, lf.data(), lf.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_lane_i32, li.data(), li.size() * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->d_gacc, 0, sizeof(double) * (size_t)h->ngroups * h->nt * 4 * kWave, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    st = upload_shared(h);
+    if (st) return st;
+    h->total_steps = 0;
+    h->pending_sigma_scale = 1.0;
+    h->pending_deweight = 0;
+    h->has_forced = false;
+    h->started = true;
+    return SMCMC_OK;
+}
+
+int smcmc_step(smcmc_engine* h, int nsteps, int metropolis) {
+    return launch(h, nsteps, metropolis, 1, nullptr, nullptr);
+}
+
+int smcmc_step_save(smcmc_engine* h, int nsteps, int metropolis, int stride, double* save_x, double* save_logl) {
+    if (!save_x || !save_logl) return fail(h, SMCMC_ERR_INVALID, "save buffers must be device pointers");
+    return launch(h, nsteps, metropolis, stride, save_x, save_logl);
+}
+
+int smcmc_force_step(smcmc_engine* h, const double* point, int broadcast) {
+    if (!h || !point) return SMCMC_ERR_INVALID;
+    const int D = h->dim, N = h->nchains;
+    const size_t NP = (size_t)h->npad;
+    std::vector<double> x(NP * h->dp, 0.0);
+    for (int d = 0; d < D; ++d)
+        for (int c = 0; c < N; ++c) x[(size_t)d * NP + c] = broadcast ? point[d] : point[(size_t)d * N + c];
+    HIP_TRY(h, hipMemcpyAsync(h->d_forced, x.data(), x.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->has_forced = true;
+    return SMCMC_OK;
+}
+
+int smcmc_moments_size(const smcmc_engine* h) { return h ? (int)npacked(h) : 0; }
+
+int smcmc_reduce_moments(smcmc_engine* h) {
+    if (!h || !h->started) return SMCMC_ERR_INVALID;
+    hipError_t e = dispatch_reduce(h->dp, h->d_gacc, h->ngroups, h->dim, h->d_moments, h->stream);
+    if (e != hipSuccess) return fail(h, SMCMC_ERR_HIP, std::string("reduce kernel launch: ") + hipGetErrorString(e));
+    HIP_TRY(h, hipMemsetAsync(h->d_gacc, 0, sizeof(double) * (size_t)h->ngroups * h->nt * 4 * kWave, h->stream));
+    return SMCMC_OK;
+}
+
+int smcmc_export_moments(smcmc_engine* h, double* dst) {
+    if (!h || !dst) return SMCMC_ERR_INVALID;
+    HIP_TRY(h, hipMemcpyAsync(dst, h->d_moments, npacked(h) * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    return SMCMC_OK;
+}
+
+int smcmc_import_moments(smcmc_engine* h, const double* src) {
+    if (!h || !src) return SMCMC_ERR_INVALID;
+    HIP_TRY(h, hipMemcpyAsync(h->d_moments, src, npacked(h) * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    return SMCMC_OK;
+}
+
+int smcmc_read_moments(smcmc_engine* h, double* out) {
+    if (!h || !out) return SMCMC_ERR_INVALID;
+    HIP_TRY(h, hipMemcpyAsync(out, h->d_moments, npacked(h) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SMCMC_OK;
+}
+
+int smcmc_apply_moments(smcmc_engine* h) {
+    if (!h || !h->started) return SMCMC_ERR_INVALID;
+    std::vector<double> M(npacked(h));
+    int st = smcmc_read_moments(h, M.data());
+    if (st) return st;
+    SharedProposal& P = *h->prop;
+    if (!(M[npacked(h) - 1] > 0.0)) return SMCMC_OK;
+    P.absorbMoments(M.data(), h->mode == SMCMC_MODE_POOLED);
+    // UpdateProposal on the shared proposal; sigma = 1 going in captures the
+    // rescale factor sqrt(old trace / new trace) the chains apply (TSimpleMCMC.H:1042)
+    const double sigmaBefore = P.sigma;
+    P.sigma = 1.0;
+    st = status_of(h, P.update(false));
+    const double scale = P.sigma;
+    P.sigma = sigmaBefore * scale;
+    if (st) return st;
+    h->pending_sigma_scale = scale;
+    h->pending_deweight = 1;
+    return upload_shared(h);
+}
+
+int smcmc_sync(smcmc_engine* h) {
+    int st = smcmc_reduce_moments(h);
+    if (st) return st;
+    return smcmc_apply_moments(h);
+}
+
+int smcmc_update_proposal(smcmc_engine* h) {
+    if (!h || !h->started) return SMCMC_ERR_INVALID;
+    SharedProposal& P = *h->prop;
+    const double sigmaBefore = P.sigma;
+    P.sigma = 1.0;
+    int st = status_of(h, P.update(false));
+    const double scale = P.sigma;
+    P.sigma = sigmaBefore * scale;
+    if (st) return st;
+    h->pending_sigma_scale *= scale;
+    h->pending_deweight = 1;
+    return upload_shared(h);
+}
+
+int smcmc_reset_proposal(smcmc_engine* h) {
+    if (!h || !h->started) return SMCMC_ERR_INVALID;
+    SharedProposal& P = *h->prop;
+    // fLastPoint of the shared proposal := chain 0's current point
+    std::vector<double> x0(h->dim);
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    for (int d = 0; d < h->dim; ++d)
+        HIP_TRY(h, hipMemcpy(&x0[d], h->d_x + (size_t)d * h->npad, sizeof(double), hipMemcpyDeviceToHost));
+    P.lastPoint = x0;
+    int st = status_of(h, P.reset());
+    if (st) return st;
+    st = broadcast_lane_i32(h, SMCMC_LANE_TRIALS, 0); if (st) return st;
+    st = broadcast_lane_i32(h, SMCMC_LANE_SUCCESSES, 0); if (st) return st;
+    st = broadcast_lane_i32(h, SMCMC_LANE_NEXT_UPDATE, P.nextUpdate); if (st) return st;
+    st = broadcast_lane_f64(h, SMCMC_LANE_ACCEPTANCE, P.acceptance); if (st) return st;
+    st = broadcast_lane_f64(h, SMCMC_LANE_ACCEPTANCE_TRIALS, P.acceptanceTrials); if (st) return st;
+    HIP_TRY(h, hipMemsetAsync(h->d_gacc, 0, sizeof(double) * (size_t)h->ngroups * h->nt * 4 * kWave, h->stream));
+    h->pending_sigma_scale = 1.0;
+    h->pending_deweight = 0;
+    return upload_shared(h);
+}
+
+int smcmc_nchains_padded(const smcmc_engine* h) { return h ? h->npad : 0; }
+int smcmc_dim_padded(const smcmc_engine* h) { return h ? h->dp : 0; }
+
+int smcmc_read_state(smcmc_engine* h, double* x, double* logl) {
+    if (!h) return SMCMC_ERR_INVALID;
+    const int D = h->dim, N = h->nchains;
+    const size_t NP = (size_t)h->npad;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (x) {
+        HIP_TRY(h, hipMemcpy2D(x, (size_t)N * sizeof(double), h->d_x, NP * sizeof(double), (size_t)N * sizeof(double),
+                               (size_t)D, hipMemcpyDeviceToHost));
+    }
+    if (logl) HIP_TRY(h, hipMemcpy(logl, h->d_lane_f64 + (size_t)SMCMC_LANE_LOGL * NP, (size_t)N * sizeof(double),
+                                   hipMemcpyDeviceToHost));
+    return SMCMC_OK;
+}
+
+int smcmc_read_lane_f64(smcmc_engine* h, int field, double* out) {
+    if (!h || !out || field < 0 || field >= SMCMC_LANE_F64_COUNT_) return SMCMC_ERR_INVALID;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipMemcpy(out, h->d_lane_f64 + (size_t)field * h->npad, (size_t)h->nchains * sizeof(double),
+                         hipMemcpyDeviceToHost));
+    return SMCMC_OK;
+}
+
+int smcmc_read_lane_i32(smcmc_engine* h, int field, int32_t* out) {
+    if (!h || !out || field < 0 || field >= SMCMC_LANE_I32_COUNT_) return SMCMC_ERR_INVALID;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipMemcpy(out, h->d_lane_i32 + (size_t)field * h->npad, (size_t)h->nchains * sizeof(int32_t),
+                         hipMemcpyDeviceToHost));
+    return SMCMC_OK;
+}
+
+int smcmc_get_center(smcmc_engine* h, double* out) {
+    if (!h || !out) return SMCMC_ERR_INVALID;
+    std::copy(h->prop->centre.begin(), h->prop->centre.end(), out);
+    return SMCMC_OK;
+}
+
+int smcmc_set_center(smcmc_engine* h, const double* in) {
+    if (!h || !in) return SMCMC_ERR_INVALID;
+    std::copy(in, in + h->dim, h->prop->centre.begin());
+    return h->started ? upload_shared(h) : SMCMC_OK;
+}
+
+int smcmc_get_covariance(smcmc_engine* h, double* out) {
+    if (!h || !out) return SMCMC_ERR_INVALID;
+    std::copy(h->prop->cov.begin(), h->prop->cov.end(), out);
+    return SMCMC_OK;
+}
+
+int smcmc_set_covariance(smcmc_engine* h, const double* in) {
+    if (!h || !in) return SMCMC_ERR_INVALID;
+    std::copy(in, in + (size_t)h->dim * h->dim, h->prop->cov.begin());
+    return SMCMC_OK;
+}
+
+int smcmc_get_decomposition(smcmc_engine* h, double* out) {
+    if (!h || !out) return SMCMC_ERR_INVALID;
+    std::copy(h->prop->decomp.begin(), h->prop->decomp.end(), out);
+    return SMCMC_OK;
+}
+
+int smcmc_state_device_ptr(smcmc_engine* h, double** x, double** logl) {
+    if (!h) return SMCMC_ERR_INVALID;
+    if (x) *x = h->d_x;
+    if (logl) *logl = h->d_lane_f64 + (size_t)SMCMC_LANE_LOGL * h->npad;
+    return SMCMC_OK;
+}
+
+}  // extern "C"

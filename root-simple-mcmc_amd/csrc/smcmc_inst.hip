@@ -1,0 +1,38 @@
+// smcmc_inst.hip -- explicit instantiations of the step kernels for one
+// (register-array size, likelihood) pair; built once per
+// -DSMCMC_DP=<n> -DSMCMC_LIKE=<k> (see root-simple-mcmc_amd/build.py).
+#include "smcmc_kernels.hip.h"
+
+#if !defined(SMCMC_DP) || !defined(SMCMC_LIKE)
+#error "compile with -DSMCMC_DP=<padded dimension> -DSMCMC_LIKE=<likelihood id>"
+#endif
+
+namespace smcmc {
+
+template <int DP, int LIKE, bool EXACT, bool FULLU, bool MOM>
+static hipError_t go(const StepParams& p, hipStream_t s) {
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(step_kernel<DP, LIKE, EXACT, FULLU, MOM>), dim3(p.npad / kWave),
+                       dim3(kWave), 0, s, p);
+    return hipGetLastError();
+}
+
+template <>
+hipError_t launch_step_like<SMCMC_DP, SMCMC_LIKE>(const StepParams& p, bool exact, bool fullu, bool mom,
+                                                  hipStream_t s) {
+    constexpr int DP = SMCMC_DP, LIKE = SMCMC_LIKE;
+    if (fullu) return mom ? go<DP, LIKE, true, true, true>(p, s) : go<DP, LIKE, true, true, false>(p, s);
+    if (exact) return mom ? go<DP, LIKE, true, false, true>(p, s) : go<DP, LIKE, true, false, false>(p, s);
+    return mom ? go<DP, LIKE, false, false, true>(p, s) : go<DP, LIKE, false, false, false>(p, s);
+}
+
+#if SMCMC_LIKE == 0
+template <>
+hipError_t launch_reduce<SMCMC_DP>(double* gacc, int ngroups, int D, double* moments, hipStream_t s) {
+    const int npk = (D + 1) * (D + 2) / 2;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(reduce_moments_kernel<SMCMC_DP>), dim3((npk + 255) / 256), dim3(256), 0, s,
+                       gacc, ngroups, D, moments);
+    return hipGetLastError();
+}
+#endif
+
+}  // namespace smcmc

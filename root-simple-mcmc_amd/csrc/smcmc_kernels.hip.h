@@ -1,0 +1,461 @@
+// smcmc_kernels.hip.h -- gfx950 kernels of the many-chain Metropolis step.
+//
+// One chain per lane, one 64-chain group per wavefront, one wavefront per
+// workgroup.  A launch advances every chain by `nsteps` calls of
+// sMCMC::TSimpleMCMC::Step() (reference TSimpleMCMC.H:370-496) without touching
+// HBM between the steps: the accepted point lives in LDS as x[dim][lane]
+// (conflict-free column per lane), the proposal in registers.
+//   A  scalar half of TProposeAdaptiveStep::UpdateState (TSimpleMCMC.H:1723-1776)
+//      per lane; in POOLED mode the current point is folded into the group's
+//      second-moment accumulator with v_mfma_f64_16x16x4_f64 whose operands are
+//      read straight from the LDS image of x (y = x - c0 formed on the fly),
+//      replacing the per-chain running covariance of TSimpleMCMC.H:1780-1820
+//   B  proposal x' = x + sigma U^T r (TSimpleMCMC.H:709-724), r from Philox +
+//      Box-Muller (include/smcmc_detmath.h), U through wave-uniform scalar loads;
+//      StepRMS window (:391-406); likelihood (:410); Metropolis test (:432-463);
+//      accept copy (:484-491) as an exec-masked LDS write
+// EXACT = the reference's un-fused operation order (mul, then add); !EXACT =
+// fused multiply-add.  Both are reproduced bit for bit by oracle/ensemble_oracle.c.
+//
+// Runtime dim <= DP: state rows >= dim are zero, U / Error are zero padded, so the
+// padded lanes of the arithmetic only ever add +-0 and need no guards.
+//
+// Compile with -ffp-contract=off.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "smcmc.h"
+#include "smcmc_detmath.h"
+
+namespace smcmc {
+
+// Register-array sizes the step kernel is instantiated for, smallest first (an
+// engine of dimension D runs the smallest DP >= D).  D + 1 <= 64 keeps the
+// moment contraction within 4 x 4 tiles.  build.py reads this list.
+#define SMCMC_FOR_EACH_DP(X) X(7) X(15) X(31) X(47) X(50) X(63)
+
+constexpr int kWave = 64;
+constexpr int kXStride = 66;   // doubles per LDS row: stride = 2 (mod 32) keeps both the lane=chain
+                               // ds_read/ds_write_b64 and the MFMA-operand ds_read_b64 conflict-free
+
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+// Wave-uniform read-only tables (U, Error, c0) are read through the constant
+// address space so that the loads become scalar (s_load into SGPRs, one fetch per
+// wavefront through the scalar cache) instead of 64 identical vector loads.
+typedef const __attribute__((address_space(4))) double* cptr_f64;
+__device__ __forceinline__ cptr_f64 as_const(const double* p) {
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+    return (cptr_f64)p;
+#pragma clang diagnostic pop
+}
+
+template <int DP>
+struct Geo {
+    static constexpr int T = (DP + 1 + 15) / 16;   // 16-row tiles covering dims 0..DP-1 plus the ones row DP
+    static constexpr int NT = T * (T + 1) / 2;     // lower-triangular tiles
+    static constexpr int NB = (DP + 3) / 4;        // Philox blocks of 4 normals
+    static constexpr int ROWS_MOMENTS = 16 * T;
+};
+
+struct StepParams {
+    int nchains, npad, dim;
+    int nsteps, metropolis;
+    uint32_t step0;            // fTotalSteps before this launch
+    uint32_t chain_offset;
+    uint64_t seed;
+    const double* U;           // [DP][DP], zero padded
+    const double* like;        // QUADFORM: Error [DP][DP] zero padded; ROSENBROCK: {b}
+    const double* c0;          // [DP] centre the moments are taken about
+    double target, acc_window, asig, max_up;
+    double acc_w, acc_wW;      // acceptance de-weighting: w = 1 - deweight, w*window; acc_w < 0 = off
+    double pending_sigma_scale;
+    int pending_deweight;
+    int per_lane_update;       // FROZEN mode: per-chain UpdateProposal schedule
+    int step_rms_window;
+    int has_forced;            // ForceStep pending: the first step proposes `forced`
+    const double* forced;      // [DP][npad]
+    double* x;                 // [DP][npad], rows >= dim stay zero
+    double* lane_f64;          // [SMCMC_LANE_F64_COUNT_][npad]
+    int32_t* lane_i32;         // [SMCMC_LANE_I32_COUNT_][npad]
+    double* gacc;              // [group][NT][4][64] moment accumulators
+    double* save_x;            // optional [slot][DP][npad]
+    double* save_logl;         // optional [slot][npad]
+    int save_stride;
+    int zero;                  // always 0; makes table addresses depend on the step so that the
+                               // compiler does not hoist (and then spill) whole tables out of the loop
+};
+
+__device__ __forceinline__ double dmin(double a, double b) { return __builtin_fmin(a, b); }
+__device__ __forceinline__ double dmax(double a, double b) { return __builtin_fmax(a, b); }
+
+// log-likelihood of the point p[0..D) held in registers.
+template <int DP, int LIKE, bool EXACT>
+__device__ __forceinline__ double loglike(const double (&p)[DP], cptr_f64 prm, int D) {
+    double logl = 0.0;
+    if constexpr (LIKE == SMCMC_LIKE_ISO_GAUSS) {
+        // README.md:57-66: logL += - 0.5*p[i]*p[i]   (padded dims add -0)
+#pragma unroll
+        for (int i = 0; i < DP; ++i) {
+            double t = -0.5 * p[i];
+            if constexpr (EXACT) logl += t * p[i];
+            else logl = SMCMC_FMA(t, p[i], logl);
+        }
+    } else if constexpr (LIKE == SMCMC_LIKE_QUADFORM) {
+        // TDummyLogLikelihood.H:24-28: logL -= 0.5*p[i]*Error(j,i)*p[j].  prm holds the
+        // TRANSPOSE of Error (prm[i][j] = Error(j,i)) so that the inner loop walks a
+        // contiguous row; rows are fetched in 16-column pieces as for U.
+#pragma unroll
+        for (int i = 0; i < DP; ++i) {
+            const double h = 0.5 * p[i];
+#pragma unroll
+            for (int jc = 0; jc < DP; jc += 16) {
+                cptr_f64 ep = prm + i * DP + jc;
+#pragma unroll
+                for (int jj = 0; jj < 16; ++jj) {
+                    const int j = jc + jj;
+                    if (j < DP) {
+                        const double e = ep[jj];
+                        if constexpr (EXACT) logl -= h * e * p[j];
+                        else logl = SMCMC_FMA(-(h * e), p[j], logl);
+                    }
+                }
+            }
+        }
+    } else {
+        // THardLogLikelihood.H:60-64
+        const double rb = prm[0];
+#pragma unroll
+        for (int i = 0; i < DP - 1; ++i) {
+            if (i < D - 1) {
+                if constexpr (EXACT) {
+                    double a = (1.0 - p[i]);
+                    double b = p[i + 1] - p[i] * p[i];
+                    logl -= a * a + rb * b * b;
+                } else {
+                    double a = 1.0 - p[i];
+                    double b = SMCMC_FMA(-p[i], p[i], p[i + 1]);
+                    double t = SMCMC_FMA(rb * b, b, a * a);
+                    logl -= t;
+                }
+            }
+        }
+    }
+    return logl;
+}
+
+template <int DP, int LIKE, bool EXACT, bool FULLU, bool MOMENTS>
+__global__ void __launch_bounds__(kWave) step_kernel(const StepParams p) {
+    constexpr int T = Geo<DP>::T;
+    constexpr int NT = Geo<DP>::NT;
+    constexpr int NB = Geo<DP>::NB;
+    constexpr int ROWS = MOMENTS ? Geo<DP>::ROWS_MOMENTS : DP;
+    __shared__ double xs[ROWS * kXStride];   // accepted point, x[row][lane]
+
+    const int lane = threadIdx.x;
+    const int group = blockIdx.x;
+    const int chain = group * kWave + lane;
+    const bool active = chain < p.nchains;
+    const int D = p.dim;
+    const size_t NP = (size_t)p.npad;
+    const uint32_t gid = p.chain_offset + (uint32_t)chain;
+    const cptr_f64 U = as_const(p.U);
+    const cptr_f64 c0 = as_const(p.c0);
+    const cptr_f64 likep = as_const(p.like);
+    double* const xcol = xs + lane;
+
+    // Lanes past the last chain hold x = c0 so that their y = x - c0 is +0 in the
+    // moment contraction; they never accept and never store.
+#pragma unroll
+    for (int d = 0; d < DP; ++d) xcol[d * kXStride] = active ? p.x[(size_t)d * NP + chain] : c0[d];
+
+    double* lf = p.lane_f64 + chain;
+    int32_t* li = p.lane_i32 + chain;
+    double logl = lf[SMCMC_LANE_LOGL * NP];
+    double sigma = lf[SMCMC_LANE_SIGMA * NP];
+    double acc_rate = lf[SMCMC_LANE_ACCEPTANCE * NP];
+    double acc_trials = lf[SMCMC_LANE_ACCEPTANCE_TRIALS * NP];
+    double rigid = lf[SMCMC_LANE_RIGIDITY * NP];
+    double last_value = lf[SMCMC_LANE_LAST_VALUE * NP];
+    double last_x0 = lf[SMCMC_LANE_LAST_X0 * NP];
+    double step_rms = lf[SMCMC_LANE_STEP_RMS * NP];
+    double logl_prop = lf[SMCMC_LANE_LOGL_PROPOSED * NP];
+    int trials = li[SMCMC_LANE_TRIALS * NP];
+    int succ = li[SMCMC_LANE_SUCCESSES * NP];
+    int next_update = li[SMCMC_LANE_NEXT_UPDATE * NP];
+    int naccept = li[SMCMC_LANE_NACCEPT * NP];
+    int rms_trials = li[SMCMC_LANE_STEP_RMS_TRIALS * NP];
+    int last_accept = li[SMCMC_LANE_LAST_ACCEPT * NP];
+
+    // adjustments left by the last pooled UpdateProposal: sigma rescale
+    // (TSimpleMCMC.H:1042) and acceptance de-weighting (:1081-1086)
+    sigma = sigma * p.pending_sigma_scale;
+    if (p.pending_deweight && p.acc_w >= 0.0) {
+        acc_trials = dmax(1.0, p.acc_w * acc_trials);
+        acc_trials = dmin(acc_trials, p.acc_wW);
+    }
+
+    f64x4 acc[MOMENTS ? NT : 1];
+    double c0r[MOMENTS ? T : 1];   // c0 of the tile rows this lane feeds to the matrix pipe
+    if constexpr (MOMENTS) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                acc[t][r] = p.gacc[(((size_t)group * NT + t) * 4 + r) * kWave + lane];
+        // row DP carries the constant 1 (sum y and the point count come out of the
+        // same contraction); the rows above it are zero
+#pragma unroll
+        for (int r = DP; r < ROWS; ++r) xcol[r * kXStride] = (r == DP && active) ? 1.0 : 0.0;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const int r = 16 * t + (lane & 15);
+            c0r[t] = (r < DP) ? p.c0[r] : 0.0;
+        }
+    }
+    __syncthreads();
+
+    double xp[DP];
+    const uint32_t aw = smcmc_accept_word((uint32_t)D);
+
+    // StepRMS window, likelihood, Metropolis test and accept copy of one step
+    // (TSimpleMCMC.H:391-406, 410-491) for the proposal held in xp.
+    auto finish_step = [&](int s, uint32_t uword) {
+        if (p.step_rms_window > 0) {
+            double sqr = 0.0;
+#pragma unroll
+            for (int d = 0; d < DP; ++d) {
+                double t = xp[d] - xcol[d * kXStride];
+                if constexpr (EXACT) sqr += t * t;
+                else sqr = SMCMC_FMA(t, t, sqr);
+            }
+            double ms = step_rms * step_rms;
+            ms *= rms_trials;
+            ms += sqr;
+            ms /= rms_trials + 1.0;
+            rms_trials = (p.step_rms_window < rms_trials + 1) ? p.step_rms_window : rms_trials + 1;
+            step_rms = __builtin_sqrt(ms);
+        }
+        logl_prop = loglike<DP, LIKE, EXACT>(xp, likep + p.zero * (s + 1), D);
+        bool take;
+        if (p.metropolis == 2) {
+            take = true;
+        } else if (!__builtin_isfinite(logl_prop) || logl_prop < -0.999999E+30) {
+            take = false;
+        } else {
+            const double delta = logl_prop - logl;
+            take = true;
+            if (delta < 0.0) {
+                if (p.metropolis == 1) take = false;
+                else {
+                    const double trial = smcmc_log_pos(smcmc_u01(uword));
+                    if (delta < trial) take = false;
+                }
+            }
+        }
+        take = take && active;
+        last_accept = take ? 1 : 0;
+        if (take) {
+            logl = logl_prop;
+            ++naccept;
+#pragma unroll
+            for (int d = 0; d < DP; ++d) xcol[d * kXStride] = xp[d];
+        }
+        if constexpr (MOMENTS) __syncthreads();   // the next step's operand reads see this step's accepts
+        if (p.save_x != nullptr && ((s + 1) % p.save_stride) == 0 && active) {
+            const size_t slot = (size_t)((s + 1) / p.save_stride - 1);
+#pragma unroll
+            for (int d = 0; d < DP; ++d) p.save_x[(slot * (size_t)DP + (size_t)d) * NP + chain] = xcol[d * kXStride];
+            p.save_logl[slot * NP + chain] = logl;
+        }
+    };
+
+    int s0 = 0;
+    if (p.has_forced && p.nsteps > 0) {
+        // ForceStep (TSimpleMCMC.H:671-678): the proposal is the forced point and the
+        // proposal state is not updated
+#pragma unroll
+        for (int d = 0; d < DP; ++d) xp[d] = p.forced[(size_t)d * NP + chain];
+        smcmc_u32x4 blk = smcmc_draw_block(p.seed, gid, (uint64_t)(p.step0 + 1u), aw >> 2, SMCMC_STREAM_STEP);
+        finish_step(0, smcmc_select_word(blk, aw & 3u));
+        s0 = 1;
+    }
+
+    for (int s = s0; s < p.nsteps; ++s) {
+        const uint64_t step = (uint64_t)(p.step0 + (uint32_t)s + 1u);   // ++fTotalSteps, :376
+
+        // ---- A: UpdateState, scalar half (TSimpleMCMC.H:1723-1776) ----
+        ++trials;
+        const double x0 = xcol[0];
+        const bool moved = (logl != last_value) || (x0 != last_x0);
+        if (moved) ++succ;
+        acc_rate *= acc_trials;
+        if (moved) acc_rate = acc_rate + 1.0;
+        acc_rate /= acc_trials + 1.0;
+        acc_trials = dmin(p.acc_window, acc_trials + 1.0);
+        if (rigid < 500.0 && rigid > 0.0) {
+            if (__builtin_fabs(acc_rate - p.target) < p.asig) {
+                rigid += 0.5 * rigid / p.acc_window;
+                rigid = dmin(200.0, rigid);
+            }
+            if (__builtin_fabs(acc_rate - p.target) > 4.0 * p.asig) {
+                rigid -= 1.618 * 0.5 * rigid / p.acc_window;
+                rigid = dmax(2.0, rigid);
+            }
+        }
+        if (rigid > 0 && rigid < 100.0) {
+            sigma *= smcmc_pow_small(acc_rate / p.target,
+                                     dmin(1.0 / 500.0, 1.0 / (rigid * p.acc_window)));
+        }
+        if constexpr (!MOMENTS) {
+            if (p.per_lane_update && moved && (--next_update) < 1) {
+                // per-chain UpdateProposal on a frozen covariance (TSimpleMCMC.H:1824-1826,
+                // 1050-1052, 1081-1086); trace unchanged => sigma and U unchanged
+                double up = 0.5 * succ;
+                next_update = (int)(p.acc_window + p.max_up - p.max_up / (up + 1.0));
+                if (p.acc_w >= 0.0) {
+                    acc_trials = dmax(1.0, p.acc_w * acc_trials);
+                    acc_trials = dmin(acc_trials, p.acc_wW);
+                }
+            }
+        }
+        last_value = logl;
+        last_x0 = x0;
+
+        // ---- B: proposal (TSimpleMCMC.H:709-724) ----
+#pragma unroll
+        for (int d = 0; d < DP; ++d) xp[d] = xcol[d * kXStride];
+        uint32_t uword = 0;
+        const cptr_f64 Us = U + p.zero * (s + 1);   // == U, but not loop invariant to the compiler
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            if constexpr (MOMENTS) {
+                // the group's second moments: the 64-chain contraction is cut into chunks
+                // spread over the Philox blocks so the matrix pipe runs under the VALU work;
+                // chains are folded in ascending order (kk ascending across b)
+#pragma unroll
+                for (int kk = 0; kk < 16; ++kk) {
+                    if (kk < (16 * b) / NB || kk >= (16 * (b + 1)) / NB) continue;
+                    double a[T];
+#pragma unroll
+                    for (int t = 0; t < T; ++t)
+                        a[t] = xs[(16 * t + (lane & 15)) * kXStride + 4 * kk + (lane >> 4)] - c0r[t];
+#pragma unroll
+                    for (int ti = 0; ti < T; ++ti)
+#pragma unroll
+                        for (int tj = 0; tj < T; ++tj)
+                            if (tj <= ti)
+                                acc[ti * (ti + 1) / 2 + tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(
+                                    a[ti], a[tj], acc[ti * (ti + 1) / 2 + tj], 0, 0, 0);
+                }
+            }
+            smcmc_u32x4 blk = smcmc_draw_block(p.seed, gid, step, (uint32_t)b, SMCMC_STREAM_STEP);
+            if ((uint32_t)b == (aw >> 2)) uword = smcmc_select_word(blk, aw & 3u);
+            double n[4];
+            smcmc_normal_pair(blk.v[0], blk.v[1], &n[0], &n[1]);
+            if (4 * b + 2 < DP) smcmc_normal_pair(blk.v[2], blk.v[3], &n[2], &n[3]);
+            else { n[2] = 0.0; n[3] = 0.0; }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = 4 * b + q;
+                if (i < DP) {
+                    const double sr = sigma * n[q];
+#pragma unroll
+                    for (int jc = 0; jc < DP; jc += 16) {
+                        if (FULLU || jc + 15 >= i) {
+                            cptr_f64 Up = Us + i * DP + jc;
+#pragma unroll
+                            for (int jj = 0; jj < 16; ++jj) {
+                                const int j = jc + jj;
+                                if (j < DP && (FULLU || j >= i)) {
+                                    const double u = Up[jj];
+                                    if constexpr (EXACT) xp[j] += sr * u;
+                                    else xp[j] = SMCMC_FMA(sr, u, xp[j]);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        if ((aw >> 2) >= (uint32_t)NB) {
+            smcmc_u32x4 blk = smcmc_draw_block(p.seed, gid, step, aw >> 2, SMCMC_STREAM_STEP);
+            uword = smcmc_select_word(blk, aw & 3u);
+        }
+        finish_step(s, uword);
+    }
+
+    if constexpr (MOMENTS) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                p.gacc[(((size_t)group * NT + t) * 4 + r) * kWave + lane] = acc[t][r];
+    }
+    if (active) {
+#pragma unroll
+        for (int d = 0; d < DP; ++d) p.x[(size_t)d * NP + chain] = xcol[d * kXStride];
+        lf[SMCMC_LANE_LOGL * NP] = logl;
+        lf[SMCMC_LANE_SIGMA * NP] = sigma;
+        lf[SMCMC_LANE_ACCEPTANCE * NP] = acc_rate;
+        lf[SMCMC_LANE_ACCEPTANCE_TRIALS * NP] = acc_trials;
+        lf[SMCMC_LANE_RIGIDITY * NP] = rigid;
+        lf[SMCMC_LANE_LAST_VALUE * NP] = last_value;
+        lf[SMCMC_LANE_LAST_X0 * NP] = last_x0;
+        lf[SMCMC_LANE_STEP_RMS * NP] = step_rms;
+        lf[SMCMC_LANE_LOGL_PROPOSED * NP] = logl_prop;
+        li[SMCMC_LANE_TRIALS * NP] = trials;
+        li[SMCMC_LANE_SUCCESSES * NP] = succ;
+        li[SMCMC_LANE_NEXT_UPDATE * NP] = next_update;
+        li[SMCMC_LANE_NACCEPT * NP] = naccept;
+        li[SMCMC_LANE_STEP_RMS_TRIALS * NP] = rms_trials;
+        li[SMCMC_LANE_LAST_ACCEPT * NP] = last_accept;
+    }
+}
+
+// Sums the per-group accumulator tiles in group order into the packed moment
+// vector M[(D+1)(D+2)/2].  One thread per packed element.
+template <int DP>
+__global__ void reduce_moments_kernel(const double* __restrict__ gacc, int ngroups, int D,
+                                      double* __restrict__ moments) {
+    constexpr int NT = Geo<DP>::NT;
+    const int npk = (D + 1) * (D + 2) / 2;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= npk) return;
+    // unpack k -> (i, j), j <= i
+    int i = (int)((__builtin_sqrt(8.0 * (double)k + 1.0) - 1.0) * 0.5);
+    while ((i + 1) * (i + 2) / 2 <= k) ++i;
+    while (i * (i + 1) / 2 > k) --i;
+    const int j = k - i * (i + 1) / 2;
+    const int ri = (i == D) ? DP : i, rj = (j == D) ? DP : j;   // the ones row sits at row DP of the tiles
+    const int ti = ri >> 4, tj = rj >> 4, ii = ri & 15, jj = rj & 15;
+    // C/D layout of v_mfma_f64_16x16x4_f64: column = lane & 15, row = (lane >> 4) + 4*reg
+    const int reg = ii >> 2;
+    const int lane = jj + 16 * (ii & 3);
+    const size_t off = ((size_t)(ti * (ti + 1) / 2 + tj) * 4 + reg) * kWave + lane;
+    const size_t gstride = (size_t)NT * 4 * kWave;
+    double s = 0.0;
+    for (int g = 0; g < ngroups; ++g) s += gacc[(size_t)g * gstride + off];
+    moments[k] = s;
+}
+
+// Host-callable launchers, one translation unit per (DP, likelihood) (smcmc_inst.hip).
+template <int DP, int LIKE> hipError_t launch_step_like(const StepParams& p, bool exact, bool fullu, bool moments,
+                                                        hipStream_t stream);
+template <int DP> hipError_t launch_reduce(double* gacc, int ngroups, int D, double* moments, hipStream_t stream);
+
+template <int DP>
+inline hipError_t launch_step(const StepParams& p, int like, bool exact, bool fullu, bool moments,
+                              hipStream_t stream) {
+    switch (like) {
+        case SMCMC_LIKE_ISO_GAUSS: return launch_step_like<DP, SMCMC_LIKE_ISO_GAUSS>(p, exact, fullu, moments, stream);
+        case SMCMC_LIKE_QUADFORM: return launch_step_like<DP, SMCMC_LIKE_QUADFORM>(p, exact, fullu, moments, stream);
+        case SMCMC_LIKE_ROSENBROCK: return launch_step_like<DP, SMCMC_LIKE_ROSENBROCK>(p, exact, fullu, moments, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace smcmc

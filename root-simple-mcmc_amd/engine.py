@@ -1,0 +1,252 @@
+"""Host-side mirror of the reference's operator interface for the Step() path.
+
+`Engine` is the many-chain counterpart of sMCMC::TSimpleMCMC<L, TProposeAdaptiveStep>
+(reference TSimpleMCMC.H:185-590): the same verbs (Start, Step, SaveStep-style
+read back, GetProposeStep()-style setters/getters named as in TSimpleMCMC.H:732-1003)
+on top of the C ABI of include/smcmc.h.  All compute happens in the HIP library.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from ._capi import (LIKE_ISO_GAUSS, LIKE_QUADFORM, LIKE_ROSENBROCK, MODE_FROZEN, MODE_POOLED, P, SmcmcError)
+
+_dp = C.POINTER(C.c_double)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(_dp)
+
+
+class Engine:
+    """N chains of dimension D advancing in lock step on one GPU."""
+
+    def __init__(self, dim, nchains=1, likelihood=LIKE_ISO_GAUSS, likelihood_params=None, seed=20240607,
+                 chain_offset=0, device=0, mode=MODE_POOLED, exact=True, stream=None):
+        self._lib = _capi.load()
+        self.dim, self.nchains = int(dim), int(nchains)
+        h = C.c_void_p()
+        st = self._lib.smcmc_create(self.dim, self.nchains, likelihood, seed, chain_offset, device, C.byref(h))
+        self._h = h
+        if st != _capi.OK:
+            msg = self._lib.smcmc_last_error(h).decode() if h else self._lib.smcmc_status_string(st).decode()
+            if h:
+                self._lib.smcmc_destroy(h)
+            self._h = None
+            raise SmcmcError(st, msg)
+        self._check(self._lib.smcmc_set_mode(self._h, mode))
+        self.set_param("EXACT_ARITHMETIC", 1.0 if exact else 0.0)
+        if likelihood_params is not None:
+            prm = _f64(likelihood_params).ravel()
+            self._check(self._lib.smcmc_set_likelihood_params(self._h, _ptr(prm), prm.size))
+        if stream is not None:
+            self.set_stream(stream)
+
+    # -- plumbing ---------------------------------------------------------
+    def _check(self, st):
+        if st != _capi.OK:
+            raise SmcmcError(st, self._lib.smcmc_last_error(self._h).decode()
+                             or self._lib.smcmc_status_string(st).decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.smcmc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream):
+        """stream: a raw hipStream_t value (e.g. torch.cuda.current_stream().cuda_stream)."""
+        self._check(self._lib.smcmc_set_stream(self._h, C.c_void_p(int(stream))))
+
+    @property
+    def nchains_padded(self):
+        return self._lib.smcmc_nchains_padded(self._h)
+
+    @property
+    def dim_padded(self):
+        return self._lib.smcmc_dim_padded(self._h)
+
+    # -- GetProposeStep() surface (TSimpleMCMC.H:732-1003) ------------------
+    def set_param(self, name, value):
+        self._check(self._lib.smcmc_set_param(self._h, P[name], float(value)))
+
+    def get_param(self, name):
+        out = C.c_double(0)
+        self._check(self._lib.smcmc_get_param(self._h, P[name], C.byref(out)))
+        return out.value
+
+    def SetGaussian(self, dim, sigma):
+        self._check(self._lib.smcmc_set_gaussian(self._h, dim, sigma))
+
+    def SetUniform(self, dim, minimum, maximum):
+        self._check(self._lib.smcmc_set_uniform(self._h, dim, minimum, maximum))
+
+    def SetCorrelation(self, dim1, dim2, correlation):
+        self._check(self._lib.smcmc_set_correlation(self._h, dim1, dim2, correlation))
+
+    def ResetCorrelations(self):
+        self._check(self._lib.smcmc_reset_correlations(self._h))
+
+    def SetCovarianceWindow(self, w): self.set_param("COVARIANCE_WINDOW", w)
+    def GetCovarianceWindow(self): return self.get_param("COVARIANCE_WINDOW")
+    def SetCovarianceUpdateDeweighting(self, d): self.set_param("COVARIANCE_DEWEIGHT", d)
+    def SetAcceptanceWindow(self, w): self.set_param("ACCEPTANCE_WINDOW", w)
+    def GetAcceptanceWindow(self): return self.get_param("ACCEPTANCE_WINDOW")
+    def SetAcceptanceUpdateDeweighting(self, d): self.set_param("ACCEPTANCE_DEWEIGHT", d)
+    def SetAcceptanceRigidity(self, r): self.set_param("ACCEPTANCE_RIGIDITY", r)
+    def GetAcceptanceRigidity(self): return self.get_param("ACCEPTANCE_RIGIDITY")
+    def SetTargetAcceptance(self, a): self.set_param("TARGET_ACCEPTANCE", a)
+    def GetTargetAcceptance(self): return self.get_param("TARGET_ACCEPTANCE")
+    def SetSigma(self, s): self.set_param("SIGMA", s)
+    def GetSigma(self): return self.get_param("SIGMA")
+    def SetMaximumCorrelation(self, c): self.set_param("MAXIMUM_CORRELATION", c)
+    def SetStepRMSWindow(self, n): self.set_param("STEP_RMS_WINDOW", n)
+    def SetNextUpdate(self, n): self.set_param("NEXT_UPDATE", n)
+    def GetNextUpdate(self): return self.get_param("NEXT_UPDATE")
+    def GetCovarianceTrials(self): return self.get_param("COVARIANCE_TRIALS")
+    def SetCovarianceTrials(self, v): self.set_param("COVARIANCE_TRIALS", v)
+    def GetEstimatedCenterTrials(self): return self.get_param("CENTER_TRIALS")
+    def SetEstimatedCenterTrials(self, v): self.set_param("CENTER_TRIALS", v)
+    def GetCovarianceTrace(self): return self.get_param("COVARIANCE_TRACE")
+
+    def UpdateProposal(self):
+        self._check(self._lib.smcmc_update_proposal(self._h))
+
+    def ResetProposal(self):
+        self._check(self._lib.smcmc_reset_proposal(self._h))
+
+    def ForceStep(self, point):
+        point = _f64(point)
+        self._check(self._lib.smcmc_force_step(self._h, _ptr(point), int(point.ndim == 1)))
+
+    def GetEstimatedCenter(self):
+        out = np.zeros(self.dim)
+        self._check(self._lib.smcmc_get_center(self._h, _ptr(out)))
+        return out
+
+    def SetEstimatedCenter(self, v):
+        v = _f64(v)
+        if v.shape != (self.dim,):
+            return False
+        self._check(self._lib.smcmc_set_center(self._h, _ptr(v)))
+        return True
+
+    # -- TSimpleMCMC surface (TSimpleMCMC.H:246-532) ------------------------
+    def Start(self, start):
+        """start: [dim] (every chain) or [dim][nchains].  False = bad start (:265-268)."""
+        start = _f64(start)
+        broadcast = int(start.ndim == 1)
+        if not broadcast and start.shape != (self.dim, self.nchains):
+            raise ValueError("start must be [dim] or [dim][nchains]")
+        st = self._lib.smcmc_start(self._h, _ptr(start), broadcast)
+        if st == _capi.ERR_BAD_START:
+            return False
+        self._check(st)
+        return True
+
+    def Step(self, nsteps=1, metropolis=0):
+        """nsteps x Step(save=false, metropolis) of every chain, one launch."""
+        self._check(self._lib.smcmc_step(self._h, int(nsteps), int(metropolis)))
+
+    def StepSave(self, nsteps, save_x_ptr, save_logl_ptr, stride=1, metropolis=0):
+        """As Step, also writing the accepted points into device buffers (raw pointers)."""
+        self._check(self._lib.smcmc_step_save(self._h, int(nsteps), int(metropolis), int(stride),
+                                              C.c_void_p(int(save_x_ptr)), C.c_void_p(int(save_logl_ptr))))
+
+    def GetAccepted(self):
+        x = np.zeros((self.dim, self.nchains))
+        self._check(self._lib.smcmc_read_state(self._h, _ptr(x), None))
+        return x
+
+    def GetAcceptedLogLikelihood(self):
+        return self.lane("logl")
+
+    def GetProposedLogLikelihood(self):
+        return self.lane("logl_proposed")
+
+    def GetStepRMS(self):
+        return self.lane("step_rms")
+
+    def lane(self, name):
+        if name in _capi.LANE_F64:
+            out = np.zeros(self.nchains)
+            self._check(self._lib.smcmc_read_lane_f64(self._h, _capi.LANE_F64[name], _ptr(out)))
+            return out
+        out = np.zeros(self.nchains, np.int32)
+        self._check(self._lib.smcmc_read_lane_i32(self._h, _capi.LANE_I32[name],
+                                                  out.ctypes.data_as(C.POINTER(C.c_int32))))
+        return out
+
+    # -- pooled adaptation ---------------------------------------------------
+    @property
+    def moments_size(self):
+        return self._lib.smcmc_moments_size(self._h)
+
+    def reduce_moments(self):
+        self._check(self._lib.smcmc_reduce_moments(self._h))
+
+    def export_moments(self, dst_device_ptr):
+        self._check(self._lib.smcmc_export_moments(self._h, C.c_void_p(int(dst_device_ptr))))
+
+    def import_moments(self, src_device_ptr):
+        self._check(self._lib.smcmc_import_moments(self._h, C.c_void_p(int(src_device_ptr))))
+
+    def apply_moments(self):
+        self._check(self._lib.smcmc_apply_moments(self._h))
+
+    def sync(self):
+        self._check(self._lib.smcmc_sync(self._h))
+
+    def read_moments(self):
+        out = np.zeros(self.moments_size)
+        self._check(self._lib.smcmc_read_moments(self._h, _ptr(out)))
+        return out
+
+    @property
+    def covariance(self):
+        out = np.zeros((self.dim, self.dim))
+        self._check(self._lib.smcmc_get_covariance(self._h, _ptr(out)))
+        return out
+
+    @property
+    def decomposition(self):
+        out = np.zeros((self.dim, self.dim))
+        self._check(self._lib.smcmc_get_decomposition(self._h, _ptr(out)))
+        return out
+
+    def state_device_ptr(self):
+        x, l = C.c_void_p(), C.c_void_p()
+        self._check(self._lib.smcmc_state_device_ptr(self._h, C.byref(x), C.byref(l)))
+        return x.value, l.value
+
+
+def selftest_detmath(kind, x, y=None, device=0):
+    lib = _capi.load()
+    x = _f64(x)
+    out = np.empty_like(x)
+    yy = _f64(y) if y is not None else None
+    st = lib.smcmc_selftest_detmath(device, kind, x.size, _ptr(x), _ptr(yy) if yy is not None else None, _ptr(out))
+    if st != _capi.OK:
+        raise SmcmcError(st, lib.smcmc_status_string(st).decode())
+    return out
+
+
+def selftest_mfma(a, b, device=0):
+    lib = _capi.load()
+    a, b = _f64(a), _f64(b)
+    K = a.shape[1]
+    c = np.zeros((16, 16))
+    st = lib.smcmc_selftest_mfma(device, K, _ptr(a), _ptr(b), _ptr(c))
+    if st != _capi.OK:
+        raise SmcmcError(st, lib.smcmc_status_string(st).decode())
+    return c

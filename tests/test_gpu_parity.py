@@ -1,0 +1,291 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle.
+
+Bars: bit-exact for every integer field and -- because oracle and kernels share
+the deterministic math of include/smcmc_detmath.h and the same operation order --
+bit-exact for every double as well (the north-star tolerance is "identical
+accept/reject sequence, log-likelihood within 1 ulp"; we hold 0 ulp).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+LIKES = {"iso": 0, "quadform": 1, "rosenbrock": 2}
+
+
+def _like_params(oracle, kind, dim):
+    prm = oracle.like_params(kind, dim)
+    return prm if prm.size else None
+
+
+def _start(kind, dim, nchains, rng):
+    if kind == 2:   # SimpleMCMC.C:147: start near the Rosenbrock mode
+        return rng.uniform(0.5, 1.5, size=(dim, nchains))
+    return np.zeros(dim)
+
+
+def _pair(gpu, oracle, dim, nchains, kind, mode, exact, seed=20240607, offset=0, setup=None):
+    prm = _like_params(oracle, kind, dim)
+    e = gpu.Engine(dim, nchains, likelihood=kind, likelihood_params=prm, seed=seed, chain_offset=offset,
+                   mode=mode, exact=exact)
+    o = oracle.Ensemble(nchains, dim, kind=kind, params=prm, seed=seed, chain_offset=offset, mode=mode,
+                        exact=exact)
+    if setup:
+        setup(e, o)
+    return e, o
+
+
+def _assert_same_state(e, o, tag=""):
+    assert np.array_equal(e.GetAccepted(), o.x), f"{tag}: accepted points differ"
+    for name in ("logl", "sigma", "acceptance", "acceptance_trials", "rigidity", "step_rms", "logl_proposed"):
+        a, b = e.lane(name), o.lane(name)
+        assert np.array_equal(a, b), f"{tag}: lane field {name} differs (max |d| = {np.max(np.abs(a - b))})"
+    for name in ("trials", "successes", "next_update", "naccept", "step_rms_trials"):
+        assert np.array_equal(e.lane(name), o.lane(name)), f"{tag}: lane field {name} differs"
+    assert np.array_equal(e.lane("last_accept").astype(np.uint8), o.lane("last_accept")), f"{tag}: accept bits"
+
+
+# ---------------------------------------------------------------- hardware facts
+@pytest.mark.parametrize("kind,name", [(0, "log"), (1, "exp"), (2, "sin2pi"), (3, "cos2pi"), (5, "sqrt")])
+def test_detmath_device_equals_host_bitwise(gpu, oracle, kind, name):
+    rng = np.random.default_rng(kind)
+    if kind == 0:
+        x = np.concatenate([np.exp(rng.uniform(-700, 700, 200000)),
+                            (rng.integers(0, 2 ** 32, 200000) + 0.5) * 2.0 ** -32, rng.uniform(0.5, 2, 100000)])
+        ref = oracle.det_log(x)
+    elif kind == 1:
+        x = np.concatenate([rng.uniform(-700, 700, 200000), rng.uniform(-0.02, 0.02, 200000)])
+        ref = oracle.det_exp(x)
+    elif kind in (2, 3):
+        x = (rng.integers(0, 2 ** 32, 400000) + 0.5) * 2.0 ** -32
+        ref = oracle.det_sincos2pi(x)[kind - 2]
+    else:
+        x = np.exp(rng.uniform(-600, 600, 400000))
+        ref = np.sqrt(x)
+    out = gpu.selftest_detmath(kind, x)
+    assert np.array_equal(out.view(np.uint64), ref.view(np.uint64)), name
+
+
+def test_detmath_pow_and_div_bitwise(gpu, oracle):
+    rng = np.random.default_rng(9)
+    x = rng.uniform(1e-3, 4.3, 300000)
+    y = rng.uniform(1e-7, 2e-3, 300000)
+    assert np.array_equal(gpu.selftest_detmath(4, x, y), oracle.det_pow_small(x, y))
+    a = np.exp(rng.uniform(-300, 300, 300000)) * rng.choice([-1.0, 1.0], 300000)
+    b = np.exp(rng.uniform(-300, 300, 300000))
+    assert np.array_equal(gpu.selftest_detmath(6, a, b), a / b)
+
+
+def test_mfma_f64_is_an_ascending_k_fma_chain(gpu):
+    """v_mfma_f64_16x16x4_f64 chained over K folds k = 0..K-1 in order, one fused
+    multiply-add per product -- the order oracle/ensemble_oracle.c defines the
+    pooled moments in.  Asymmetric operands catch a transposed C layout."""
+    import ctypes
+    libm = ctypes.CDLL("libm.so.6")
+    libm.fma.restype = ctypes.c_double
+    libm.fma.argtypes = [ctypes.c_double] * 3
+    rng = np.random.default_rng(3)
+    K = 64
+    a = rng.standard_normal((16, K)) * np.exp(rng.uniform(-8, 8, (16, K)))
+    b = rng.standard_normal((K, 16)) * np.exp(rng.uniform(-8, 8, (K, 16)))
+    c = gpu.selftest_mfma(a, b)
+    ref = np.zeros((16, 16))
+    for i in range(16):
+        for j in range(16):
+            s = 0.0
+            for k in range(K):
+                s = libm.fma(a[i, k], b[k, j], s)
+            ref[i, j] = s
+    assert np.array_equal(c, ref)
+
+
+# ---------------------------------------------------------------- frozen mode
+@pytest.mark.parametrize("dim,nchains,steps", [(2, 1, 300), (5, 70, 400), (7, 64, 200), (8, 130, 150),
+                                                (20, 65, 120), (50, 128, 60), (63, 64, 30)])
+@pytest.mark.parametrize("exact", [True, False])
+def test_frozen_iso_matches_oracle(gpu, oracle, dim, nchains, steps, exact):
+    e, o = _pair(gpu, oracle, dim, nchains, 0, gpu.MODE_FROZEN, exact)
+    assert e.Start(np.zeros(dim)) and o.start(np.zeros(dim))
+    _assert_same_state(e, o, "after start")
+    for chunk in (1, 1, steps // 3, steps - steps // 3 - 2):
+        e.Step(chunk)
+        o.step(chunk)
+        _assert_same_state(e, o, f"after +{chunk} steps")
+
+
+def test_frozen_chain_is_a_reference_chain(gpu, oracle):
+    """Every lane of the FROZEN engine is bit for bit the single-chain restatement of
+    TSimpleMCMC<L,TProposeAdaptiveStep> with SetCovarianceFrozen(true), including the
+    per-chain UpdateProposal schedule (short acceptance window forces many updates)."""
+    dim, nchains, steps = 5, 96, 3000
+    e = gpu.Engine(dim, nchains, mode=gpu.MODE_FROZEN)
+    e.SetAcceptanceWindow(50)
+    assert e.Start(np.zeros(dim))
+    e.Step(steps)
+    x = e.GetAccepted()
+    for ch in (0, 1, 63, 64, 95):
+        c = oracle.Chain(dim, chain_id=ch)
+        c.set_covariance_frozen(1)
+        c.set_acceptance_window(50.0)
+        assert c.start(np.zeros(dim))
+        c.run_quiet(steps)
+        sc = c.scalars
+        assert np.array_equal(c.accepted, x[:, ch])
+        assert sc["sigma"] == e.lane("sigma")[ch]
+        assert sc["acceptance"] == e.lane("acceptance")[ch]
+        assert sc["acceptance_trials"] == e.lane("acceptance_trials")[ch]
+        assert sc["next_update"] == e.lane("next_update")[ch]
+        assert sc["trials"] == e.lane("trials")[ch] and sc["successes"] == e.lane("successes")[ch]
+        assert sc["step_rms"] == e.lane("step_rms")[ch]
+        assert sc["update_count"] > 3
+
+
+@pytest.mark.parametrize("kind,dim,nchains,steps", [(1, 5, 70, 300), (1, 20, 64, 80), (1, 50, 64, 25),
+                                                     (2, 6, 70, 300), (2, 31, 65, 100), (2, 50, 64, 40)])
+@pytest.mark.parametrize("exact", [True, False])
+def test_frozen_other_likelihoods(gpu, oracle, kind, dim, nchains, steps, exact):
+    rng = np.random.default_rng(dim)
+    e, o = _pair(gpu, oracle, dim, nchains, kind, gpu.MODE_FROZEN, exact)
+    x0 = _start(kind, dim, nchains, rng)
+    assert e.Start(x0) and o.start(x0)
+    e.Step(steps)
+    o.step(steps)
+    _assert_same_state(e, o, f"kind {kind}")
+
+
+def test_metropolis_modes_and_offsets(gpu, oracle):
+    for metropolis in (1, 2):
+        e, o = _pair(gpu, oracle, 5, 66, 0, gpu.MODE_FROZEN, True, seed=7, offset=640)
+        e.Start(np.full(5, 0.3)); o.start(np.full(5, 0.3))
+        e.Step(50, metropolis); o.step(50, metropolis)
+        _assert_same_state(e, o, f"metropolis {metropolis}")
+
+
+def test_sharding_is_invisible(gpu):
+    """Chains are keyed on their global id: two half-ensembles with chain_offset give
+    the chains of the whole one (FROZEN mode, no exchange step)."""
+    dim, n, steps = 10, 256, 100
+    whole = gpu.Engine(dim, n, mode=gpu.MODE_FROZEN); whole.Start(np.zeros(dim)); whole.Step(steps)
+    lo = gpu.Engine(dim, n // 2, mode=gpu.MODE_FROZEN); lo.Start(np.zeros(dim)); lo.Step(steps)
+    hi = gpu.Engine(dim, n // 2, chain_offset=n // 2, mode=gpu.MODE_FROZEN); hi.Start(np.zeros(dim)); hi.Step(steps)
+    x = whole.GetAccepted()
+    assert np.array_equal(x[:, : n // 2], lo.GetAccepted())
+    assert np.array_equal(x[:, n // 2:], hi.GetAccepted())
+
+
+# ---------------------------------------------------------------- pooled mode
+@pytest.mark.parametrize("dim,nchains,window,nwin", [(5, 70, 16, 6), (7, 64, 8, 4), (20, 130, 10, 4),
+                                                      (50, 192, 6, 3), (63, 64, 4, 2)])
+@pytest.mark.parametrize("exact", [True, False])
+def test_pooled_iso_matches_oracle(gpu, oracle, dim, nchains, window, nwin, exact):
+    e, o = _pair(gpu, oracle, dim, nchains, 0, gpu.MODE_POOLED, exact)
+    assert e.Start(np.zeros(dim)) and o.start(np.zeros(dim))
+    for w in range(nwin):
+        e.Step(window)
+        o.step(window)
+        _assert_same_state(e, o, f"window {w}")
+        e.reduce_moments()
+        m_gpu = e.read_moments()
+        m_cpu = o.reduce_moments()
+        assert np.array_equal(m_gpu, m_cpu), f"window {w}: moments differ, max rel {np.max(np.abs(m_gpu - m_cpu))}"
+        assert m_gpu[-1] == nchains * window
+        e.apply_moments()
+        o.apply_moments(m_cpu)
+        assert np.array_equal(e.covariance, o.covariance)
+        assert np.array_equal(e.GetEstimatedCenter(), o.center)
+        assert np.array_equal(e.decomposition, o.decomposition)
+    e.Step(3); o.step(3)
+    _assert_same_state(e, o, "after the last sync")
+
+
+def test_pooled_split_launches_equal_one_launch(gpu):
+    """The moment accumulators persist across launches: 12 x Step(1) == Step(12)."""
+    a = gpu.Engine(9, 100); a.Start(np.zeros(9)); a.Step(12); a.reduce_moments()
+    b = gpu.Engine(9, 100); b.Start(np.zeros(9))
+    for _ in range(12):
+        b.Step(1)
+    b.reduce_moments()
+    assert np.array_equal(a.read_moments(), b.read_moments())
+    assert np.array_equal(a.GetAccepted(), b.GetAccepted())
+
+
+def test_pooled_rosenbrock_and_quadform(gpu, oracle):
+    for kind, dim in ((2, 6), (1, 5)):
+        rng = np.random.default_rng(kind)
+        e, o = _pair(gpu, oracle, dim, 128, kind, gpu.MODE_POOLED, True)
+        x0 = _start(kind, dim, 128, rng)
+        assert e.Start(x0) and o.start(x0)
+        for w in range(4):
+            e.Step(20); o.step(20)
+            e.sync(); o.sync()
+        e.Step(5); o.step(5)
+        _assert_same_state(e, o, f"kind {kind}")
+        assert np.array_equal(e.decomposition, o.decomposition)
+
+
+# ---------------------------------------------------------------- boundary behaviour
+def test_bad_start_is_reported(gpu):
+    e = gpu.Engine(4, 10, likelihood=2, likelihood_params=[100.0])
+    assert e.Start(np.full(4, 1e6)) is False       # logL < -0.999999E+10 (TSimpleMCMC.H:265-268)
+    assert e.Start(np.ones(4)) is True
+
+
+def test_step_before_start_raises(gpu):
+    e = gpu.Engine(4, 10)
+    with pytest.raises(gpu.SmcmcError) as err:
+        e.Step(1)
+    assert "Uninitialized starting point" in str(err.value)   # TSimpleMCMC.H:371-374
+
+
+def test_force_step(gpu):
+    e = gpu.Engine(5, 70, mode=gpu.MODE_FROZEN)
+    e.Start(np.zeros(5))
+    e.Step(10)
+    trials = e.lane("trials").copy()
+    target = np.full(5, 0.25)
+    e.ForceStep(target)
+    e.Step(1, 2)                                   # Step(false, 2): accept everything
+    assert np.array_equal(e.GetAccepted(), np.repeat(target[:, None], 70, axis=1))
+    assert np.array_equal(e.lane("trials"), trials)            # proposal state untouched (:671-678)
+    assert np.allclose(e.GetAcceptedLogLikelihood(), -0.5 * 5 * 0.25 ** 2)
+
+
+def test_save_buffer(gpu):
+    import torch
+    dim, n, steps, stride = 5, 70, 20, 4
+    e = gpu.Engine(dim, n, mode=gpu.MODE_FROZEN)
+    e.Start(np.zeros(dim))
+    npad, dpad = e.nchains_padded, e.dim_padded
+    sx = torch.zeros((steps // stride, dpad, npad), dtype=torch.float64, device="cuda")
+    sl = torch.zeros((steps // stride, npad), dtype=torch.float64, device="cuda")
+    ref = gpu.Engine(dim, n, mode=gpu.MODE_FROZEN)
+    ref.Start(np.zeros(dim))
+    e.StepSave(steps, sx.data_ptr(), sl.data_ptr(), stride=stride)
+    torch.cuda.synchronize()
+    for slot in range(steps // stride):
+        ref.Step(stride)
+        assert np.array_equal(sx[slot, :dim, :n].cpu().numpy(), ref.GetAccepted())
+        assert np.array_equal(sl[slot, :n].cpu().numpy(), ref.GetAcceptedLogLikelihood())
+
+
+# ---------------------------------------------------------------- full-size properties
+def test_full_size_d50_properties(gpu):
+    """BASELINE config 2 shape (D=50, 65 536 chains): size-independent properties."""
+    dim, n = 50, 65536
+    a = gpu.Engine(dim, n, seed=11); a.Start(np.zeros(dim))
+    b = gpu.Engine(dim, n, seed=11); b.Start(np.zeros(dim))
+    for _ in range(3):
+        a.Step(64); b.Step(64)
+        a.reduce_moments(); b.reduce_moments()
+        ma, mb = a.read_moments(), b.read_moments()
+        assert np.array_equal(ma, mb)                              # run-to-run deterministic
+        assert ma[-1] == n * 64                                    # every chain-step was folded in
+        a.apply_moments(); b.apply_moments()
+    assert np.array_equal(a.GetAccepted(), b.GetAccepted())
+    x = a.GetAccepted()
+    logl = a.GetAcceptedLogLikelihood()
+    assert np.allclose(logl, -0.5 * np.sum(x * x, axis=0), rtol=1e-12)   # state and logL agree
+    acc = a.lane("naccept").sum() / (n * 192)
+    assert 0.1 < acc < 0.6
+    # the pooled covariance moves toward the target's (identity): trace ~ D
+    assert abs(np.trace(a.covariance) / dim - 1.0) < 0.25

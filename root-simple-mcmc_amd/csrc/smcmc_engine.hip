@@ -455,7 +455,7 @@ int smcmc_start(smcmc_engine* h, const double* x0, int broadcast) {
         p.has_forced = 1; p.forced = h->d_forced;
         p.x = h->d_x; p.lane_f64 = h->d_lane_f64; p.lane_i32 = h->d_lane_i32; p.gacc = h->d_gacc;
         p.save_stride = 1;
-        hipError_t e = dispatch_step(h->dp, p, h->likelihood, true, false, false, h->stream);
+        hipError_t e = dispatch_step(h->dp, p, h->likelihood, h->exact, false, false, h->stream);
         if (e != hipSuccess) return fail(h, SMCMC_ERR_HIP, std::string("start kernel launch: ") + hipGetErrorString(e));
     }
     std::vector<double> logl(NP, 0.0);

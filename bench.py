@@ -57,6 +57,8 @@ def main():
     ap.add_argument("--window", type=int, default=WINDOW)
     ap.add_argument("--fast", action="store_true", help="fused multiply-add arithmetic (not the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--frozen", action="store_true", help="diagnostic: frozen covariance, no moment fold")
+    ap.add_argument("--dim", type=int, default=DIM, help="diagnostic: other dimension (not the headline)")
     args = ap.parse_args()
 
     import torch
@@ -76,10 +78,12 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
     stream = torch.cuda.current_stream()
-    eng = pkg.Engine(DIM, args.chains, likelihood=pkg.LIKE_ISO_GAUSS, seed=20240607,
-                     chain_offset=rank * args.chains, device=local, mode=pkg.MODE_POOLED,
+    dim = args.dim
+    eng = pkg.Engine(dim, args.chains, likelihood=pkg.LIKE_ISO_GAUSS, seed=20240607,
+                     chain_offset=rank * args.chains, device=local,
+                     mode=pkg.MODE_FROZEN if args.frozen else pkg.MODE_POOLED,
                      exact=not args.fast, stream=stream.cuda_stream)
-    assert eng.Start(np.zeros(DIM))
+    assert eng.Start(np.zeros(dim))
     mbuf = torch.zeros(eng.moments_size, dtype=torch.float64, device="cuda")
 
     kernel_ms = []
@@ -92,6 +96,8 @@ def main():
         if timed:
             e1.record(stream)
             kernel_ms.append((e0, e1))
+        if args.frozen:
+            return
         eng.reduce_moments()
         if world > 1:
             eng.export_moments(mbuf.data_ptr())
@@ -122,7 +128,8 @@ def main():
     value = chain_steps / dt
     kms = float(np.mean([a.elapsed_time(b) for a, b in kernel_ms]))
     per_launch = float(args.chains) * args.window
-    achieved = per_launch * BYTES_PER_CHAIN_STEP / (kms * 1e-3) / 1e9
+    bytes_cs = 16 * dim + 16
+    achieved = per_launch * bytes_cs / (kms * 1e-3) / 1e9
 
     naccept = eng.lane("naccept").astype(np.float64)
     total_steps = eng.get_param("TOTAL_STEPS")
@@ -133,14 +140,14 @@ def main():
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "TDummyLogLikelihood README form (iso-Gaussian) D=50, 65536 chains/GPU, "
                                "TProposeAdaptiveStep pooled covariance, window=%d steps/launch" % args.window,
-                   "dim": DIM, "chains_per_gpu": args.chains, "window": args.window,
+                   "dim": dim, "mode": "frozen" if args.frozen else "pooled", "chains_per_gpu": args.chains, "window": args.window,
                    "arithmetic": "fused" if args.fast else "reference-order", "seed": 20240607},
         "accept_rate": float(naccept.sum() / (total_steps * args.chains)),
         "mean_sigma": float(eng.lane("sigma").mean()),
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                      "kernel": "step_kernel<50,ISO,%s,tri,moments>" % ("fused" if args.fast else "exact"),
-                     "kernel_ms": kms, "bytes_per_chain_step": BYTES_PER_CHAIN_STEP,
+                     "kernel_ms": kms, "bytes_per_chain_step": bytes_cs,
                      "chain_steps_per_launch": per_launch},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

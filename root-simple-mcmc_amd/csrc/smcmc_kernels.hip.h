@@ -26,6 +26,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "smcmc.h"
 #include "smcmc_detmath.h"
 
@@ -46,6 +48,9 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 // address space so that the loads become scalar (s_load into SGPRs, one fetch per
 // wavefront through the scalar cache) instead of 64 identical vector loads.
 typedef const __attribute__((address_space(4))) double* cptr_f64;
+typedef const __attribute__((address_space(3))) double* lds_cptr_f64;
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(3))) f64x2* lds_cptr_f64x2;
 __device__ __forceinline__ cptr_f64 as_const(const double* p) {
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Wold-style-cast"
@@ -53,13 +58,79 @@ __device__ __forceinline__ cptr_f64 as_const(const double* p) {
 #pragma clang diagnostic pop
 }
 
+
+// compile-time loop: f(std::integral_constant<int, 0>) ... f(<N-1>)
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for_impl(F& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for_impl<I + 1, N>(f);
+    }
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl<0, N>(f); }
+
+constexpr int kPiece = 16;   // columns of U consumed per scheduling region (8 x ds_read_b128)
+
 template <int DP>
 struct Geo {
     static constexpr int T = (DP + 1 + 15) / 16;   // 16-row tiles covering dims 0..DP-1 plus the ones row DP
     static constexpr int NT = T * (T + 1) / 2;     // lower-triangular tiles
     static constexpr int NB = (DP + 3) / 4;        // Philox blocks of 4 normals
-    static constexpr int ROWS_MOMENTS = 16 * T;
+    static constexpr int ROWS_MOMENTS = DP + 1;    // LDS rows of x: the dims and the ones row (zero rows are synthesized)
 };
+
+// LDS image of the decomposition: row i keeps columns j0(i)..DP-1 (j0 = i rounded
+// down to even for the triangular factor, 0 for a full matrix), padded to an even
+// length so that every row starts 16-byte aligned (ds_read_b128 = two columns).
+template <int DP, bool FULLU>
+struct ULayout {
+    static constexpr int DPE = DP + (DP & 1);       // DP rounded up to even
+    static constexpr int j0(int i) { return FULLU ? 0 : (i & ~1); }
+    static constexpr int len(int i) { return DPE - j0(i); }
+    // closed form of sum_{r<i} len(r) (no loop: must fold once the caller's loops unroll)
+    static constexpr int off(int i) {
+        return FULLU ? i * DPE
+                     : i * DPE - ((i & 1) ? 2 * (i / 2) * (i / 2) : 2 * (i / 2) * (i / 2 - 1));
+    }
+    static constexpr int SIZE = off(DP);
+};
+
+// The pieces (row, first column) that the rows of Philox block B contribute, in
+// the order they are consumed.
+template <int DP, bool FULLU, int B>
+struct UPieces {
+    typedef ULayout<DP, FULLU> UL;
+    static constexpr int rows() { return (4 * B + 4 <= DP) ? 4 : (DP - 4 * B); }
+    static constexpr int per_row(int i) { return (UL::len(i) + kPiece - 1) / kPiece; }
+    static constexpr int count() {
+        int n = 0;
+        for (int q = 0; q < rows(); ++q) n += per_row(4 * B + q);
+        return n;
+    }
+    static constexpr int COUNT = count();
+    static constexpr int row(int r) {
+        int i = 4 * B;
+        while (r >= per_row(i)) { r -= per_row(i); ++i; }
+        return i;
+    }
+    static constexpr int col(int r) {
+        int i = 4 * B;
+        while (r >= per_row(i)) { r -= per_row(i); ++i; }
+        return UL::j0(i) + r * kPiece;
+    }
+};
+
+// kPiece columns of row i starting at column c (c - j0(i) is even: 16-byte aligned reads).
+template <int DP, bool FULLU, int i, int c>
+__device__ __forceinline__ void load_piece(lds_cptr_f64 up, f64x2 (&dst)[kPiece / 2]) {
+    typedef ULayout<DP, FULLU> UL;
+#pragma unroll
+    for (int k = 0; k < kPiece / 2; ++k) {
+        if (c + 2 * k < UL::DPE)
+            dst[k] = *(volatile lds_cptr_f64x2)(up + UL::off(i) + (c - UL::j0(i)) + 2 * k);
+    }
+}
 
 struct StepParams {
     int nchains, npad, dim;
@@ -148,12 +219,14 @@ __device__ __forceinline__ double loglike(const double (&p)[DP], cptr_f64 prm, i
 }
 
 template <int DP, int LIKE, bool EXACT, bool FULLU, bool MOMENTS>
-__global__ void __launch_bounds__(kWave) step_kernel(const StepParams p) {
+__global__ void __launch_bounds__(kWave, 2) step_kernel(const StepParams p) {
     constexpr int T = Geo<DP>::T;
     constexpr int NT = Geo<DP>::NT;
     constexpr int NB = Geo<DP>::NB;
     constexpr int ROWS = MOMENTS ? Geo<DP>::ROWS_MOMENTS : DP;
+    typedef ULayout<DP, FULLU> UL;
     __shared__ double xs[ROWS * kXStride];   // accepted point, x[row][lane]
+    __shared__ __attribute__((aligned(16))) double us[UL::SIZE];   // decomposition, every lane reads the same word
 
     const int lane = threadIdx.x;
     const int group = blockIdx.x;
@@ -162,7 +235,6 @@ __global__ void __launch_bounds__(kWave) step_kernel(const StepParams p) {
     const int D = p.dim;
     const size_t NP = (size_t)p.npad;
     const uint32_t gid = p.chain_offset + (uint32_t)chain;
-    const cptr_f64 U = as_const(p.U);
     const cptr_f64 c0 = as_const(p.c0);
     const cptr_f64 likep = as_const(p.like);
     double* const xcol = xs + lane;
@@ -198,8 +270,18 @@ __global__ void __launch_bounds__(kWave) step_kernel(const StepParams p) {
         acc_trials = dmin(acc_trials, p.acc_wW);
     }
 
+    // stage U: lane-strided copy of each kept row segment
+#pragma unroll
+    for (int i = 0; i < DP; ++i) {
+        for (int k = lane; k < UL::len(i); k += kWave) {
+            const int j = UL::j0(i) + k;
+            us[UL::off(i) + k] = (j < DP) ? p.U[i * DP + j] : 0.0;
+        }
+    }
+
     f64x4 acc[MOMENTS ? NT : 1];
     double c0r[MOMENTS ? T : 1];   // c0 of the tile rows this lane feeds to the matrix pipe
+    int xrow[MOMENTS ? T : 1];     // LDS row (clamped to the ones row) of those tile rows
     if constexpr (MOMENTS) {
 #pragma unroll
         for (int t = 0; t < NT; ++t)
@@ -207,13 +289,13 @@ __global__ void __launch_bounds__(kWave) step_kernel(const StepParams p) {
             for (int r = 0; r < 4; ++r)
                 acc[t][r] = p.gacc[(((size_t)group * NT + t) * 4 + r) * kWave + lane];
         // row DP carries the constant 1 (sum y and the point count come out of the
-        // same contraction); the rows above it are zero
-#pragma unroll
-        for (int r = DP; r < ROWS; ++r) xcol[r * kXStride] = (r == DP && active) ? 1.0 : 0.0;
+        // same contraction); tile rows above it are zero and are not stored
+        xcol[DP * kXStride] = active ? 1.0 : 0.0;
 #pragma unroll
         for (int t = 0; t < T; ++t) {
             const int r = 16 * t + (lane & 15);
             c0r[t] = (r < DP) ? p.c0[r] : 0.0;
+            xrow[t] = ((r <= DP) ? r : DP) * kXStride + (lane >> 4);
         }
     }
     __syncthreads();
@@ -329,9 +411,13 @@ __global__ void __launch_bounds__(kWave) step_kernel(const StepParams p) {
 #pragma unroll
         for (int d = 0; d < DP; ++d) xp[d] = xcol[d * kXStride];
         uint32_t uword = 0;
-        const cptr_f64 Us = U + p.zero * (s + 1);   // == U, but not loop invariant to the compiler
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
+        // The LDS image of U never changes, so the compiler would hoist all of its reads out
+        // of the step loop and spill them; reading through a pointer it cannot see through
+        // keeps them inside the step.
+        lds_cptr_f64 up = (lds_cptr_f64)us;
+        asm volatile("" : "+v"(up));
+        static_for<NB>([&](auto bc) {
+            constexpr int b = decltype(bc)::value;
             if constexpr (MOMENTS) {
                 // the group's second moments: the 64-chain contraction is cut into chunks
                 // spread over the Philox blocks so the matrix pipe runs under the VALU work;
@@ -341,8 +427,10 @@ __global__ void __launch_bounds__(kWave) step_kernel(const StepParams p) {
                     if (kk < (16 * b) / NB || kk >= (16 * (b + 1)) / NB) continue;
                     double a[T];
 #pragma unroll
-                    for (int t = 0; t < T; ++t)
-                        a[t] = xs[(16 * t + (lane & 15)) * kXStride + 4 * kk + (lane >> 4)] - c0r[t];
+                    for (int t = 0; t < T; ++t) {
+                        a[t] = xs[xrow[t] + 4 * kk] - c0r[t];
+                        if (16 * t + 15 > DP) a[t] = (16 * t + (lane & 15) <= DP) ? a[t] : 0.0;   // rows past the ones row
+                    }
 #pragma unroll
                     for (int ti = 0; ti < T; ++ti)
 #pragma unroll
@@ -352,35 +440,56 @@ __global__ void __launch_bounds__(kWave) step_kernel(const StepParams p) {
                                     a[ti], a[tj], acc[ti * (ti + 1) / 2 + tj], 0, 0, 0);
                 }
             }
+            // U rows 4b..4b+3 are consumed in pieces of kPiece columns; the LDS reads of a
+            // piece are issued one piece ahead of its use (the first one before the random
+            // numbers are made), and each piece is its own scheduling region: the scheduler
+            // otherwise issues every read of the step up front and spills hundreds of registers.
+            typedef UPieces<DP, FULLU, b> PC;
+            f64x2 cur[kPiece / 2], nxt[kPiece / 2];
+            {
+                constexpr int i0 = PC::row(0), c0p = PC::col(0);
+                load_piece<DP, FULLU, i0, c0p>(up, cur);
+            }
+
             smcmc_u32x4 blk = smcmc_draw_block(p.seed, gid, step, (uint32_t)b, SMCMC_STREAM_STEP);
             if ((uint32_t)b == (aw >> 2)) uword = smcmc_select_word(blk, aw & 3u);
             double n[4];
             smcmc_normal_pair(blk.v[0], blk.v[1], &n[0], &n[1]);
-            if (4 * b + 2 < DP) smcmc_normal_pair(blk.v[2], blk.v[3], &n[2], &n[3]);
+            if constexpr (4 * b + 2 < DP) smcmc_normal_pair(blk.v[2], blk.v[3], &n[2], &n[3]);
             else { n[2] = 0.0; n[3] = 0.0; }
+            double sr[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int i = 4 * b + q;
-                if (i < DP) {
-                    const double sr = sigma * n[q];
+            for (int q = 0; q < 4; ++q) sr[q] = sigma * n[q];
+            __builtin_amdgcn_sched_barrier(0);
+
+            static_for<PC::COUNT>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                constexpr int i = PC::row(r), c = PC::col(r);
+                if constexpr (r + 1 < PC::COUNT) {
+                    constexpr int i1 = PC::row(r + 1), c1 = PC::col(r + 1);
+                    load_piece<DP, FULLU, i1, c1>(up, nxt);
+                }
+                const double srow = sr[i - 4 * b];
 #pragma unroll
-                    for (int jc = 0; jc < DP; jc += 16) {
-                        if (FULLU || jc + 15 >= i) {
-                            cptr_f64 Up = Us + i * DP + jc;
-#pragma unroll
-                            for (int jj = 0; jj < 16; ++jj) {
-                                const int j = jc + jj;
-                                if (j < DP && (FULLU || j >= i)) {
-                                    const double u = Up[jj];
-                                    if constexpr (EXACT) xp[j] += sr * u;
-                                    else xp[j] = SMCMC_FMA(sr, u, xp[j]);
-                                }
-                            }
-                        }
+                for (int k = 0; k < kPiece; ++k) {
+                    const int j = c + k;
+                    if (j < DP && (FULLU || j >= i)) {
+                        const double u = cur[k / 2][k & 1];
+                        if constexpr (EXACT) xp[j] += srow * u;
+                        else xp[j] = SMCMC_FMA(srow, u, xp[j]);
+                        // pins this update between the (ordered) LDS reads around it; without it
+                        // the arithmetic of the whole step sinks below all the reads, which then
+                        // have to be spilled
+                        asm volatile("" : "+v"(xp[j]));
                     }
                 }
-            }
-        }
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (r + 1 < PC::COUNT) {
+#pragma unroll
+                    for (int k = 0; k < kPiece / 2; ++k) cur[k] = nxt[k];
+                }
+            });
+        });
         if ((aw >> 2) >= (uint32_t)NB) {
             smcmc_u32x4 blk = smcmc_draw_block(p.seed, gid, step, aw >> 2, SMCMC_STREAM_STEP);
             uword = smcmc_select_word(blk, aw & 3u);

@@ -1,0 +1,213 @@
+"""Pins the CPU oracle (oracle/oracle_core.h) against everything the reference
+itself fixes: the reference has no tests or golden vectors,
+so these are the known-answer values of SURVEY.md section 8c -- defaults after
+Start, the lag / spurious-first-reject quirk of the proposal bookkeeping, the
+analytic posteriors of the shipped targets -- plus algebraic properties of the
+restated pieces.  Parity against the reference proper stays UNPINNED."""
+import numpy as np
+import pytest
+
+
+def test_defaults_after_start_d5(oracle):
+    # sigma=1/sqrt(5), W=5^1.5+1000, nextUpdate=1011, covWindow=245, T=5, A=0.234
+    c = oracle.Chain(5)
+    assert c.start(np.zeros(5))
+    s = c.scalars
+    assert s["sigma"] == np.sqrt(1.0 / 5)
+    assert s["acceptance_window"] == 5 ** 1.5 + 1000
+    assert s["next_update"] == 1011
+    assert s["cov_window"] == 245
+    assert s["acceptance_trials"] == 5.0
+    assert s["acceptance"] == 0.234 and s["target"] == 0.234
+    assert s["trials"] == 0 and s["successes"] == 0
+    assert np.array_equal(c.covariance, np.eye(5)) and np.array_equal(c.decomposition, np.eye(5))
+    assert np.array_equal(c.center, np.zeros(5))
+
+
+@pytest.mark.parametrize("dim,target", [(1, 0.44), (4, 0.44), (5, 0.234), (50, 0.234)])
+def test_default_target_acceptance(oracle, dim, target):
+    c = oracle.Chain(dim)
+    c.start(np.zeros(dim))
+    assert c.scalars["target"] == target            # TSimpleMCMC.H:1709-1710
+    assert c.scalars["cov_window"] == min(dim ** 3 + 100 + 4 * dim, np.sqrt(1.0 / np.finfo(float).eps))
+
+
+def test_bookkeeping_lags_by_one_call(oracle):
+    """UpdateState runs at the start of the NEXT call, so fTrials /
+    fSuccesses lag Step()'s return value by one call and the very first call records
+    a spurious rejected trial."""
+    c = oracle.Chain(5)
+    c.start(np.zeros(5))
+    out = c.run(200)
+    acc = out["accepted"].astype(int)
+    assert out["trials"][0] == 1 and out["successes"][0] == 0
+    assert np.array_equal(out["trials"], np.arange(1, 201))
+    assert np.array_equal(out["successes"][1:], np.cumsum(acc)[:-1])
+    # rejected steps keep the accepted log-likelihood
+    la = out["logl_accepted"]
+    assert np.all((np.diff(la) != 0) == (acc[1:] == 1))
+
+
+def test_start_rejects_bad_points(oracle):
+    c = oracle.Chain(4, kind=oracle.LIKE_ROSENBROCK)
+    assert not c.start(np.full(4, 1e6))              # logL < -0.999999E+10 (TSimpleMCMC.H:265-268)
+    c = oracle.Chain(4)
+    assert not c.start(np.array([np.nan, 0, 0, 0]))
+
+
+def test_likelihood_functors(oracle):
+    rng = np.random.default_rng(0)
+    p = rng.standard_normal(7)
+    assert np.isclose(oracle.loglike(oracle.LIKE_ISO, p), -0.5 * np.sum(p * p), rtol=1e-15)
+    assert oracle.loglike(oracle.LIKE_ROSENBROCK, np.ones(6)) == 0.0          # mode (1,...,1), logL = 0
+    q = rng.standard_normal(6)
+    ref = -sum((1 - q[i]) ** 2 + 100.0 * (q[i + 1] - q[i] ** 2) ** 2 for i in range(5))
+    assert np.isclose(oracle.loglike(oracle.LIKE_ROSENBROCK, q), ref, rtol=1e-14)
+    cov, err = oracle.dummy_error_matrix(7)
+    assert np.isclose(oracle.loglike(oracle.LIKE_QUADFORM, p), -0.5 * p @ err @ p, rtol=1e-9)
+
+
+def test_dummy_likelihood_init_d100(oracle):
+    # SURVEY.md section 2 probe: Error(0,0)=Error(99,99)~5e5, Error(0,99)~-5e5, rest identity
+    cov, err = oracle.dummy_error_matrix(100)
+    assert cov[0, 99] == cov[99, 0] and abs(cov[0, 99] - 0.999999) < 1e-15
+    off = cov - np.eye(100)
+    off[0, 99] = off[99, 0] = 0
+    assert not off.any()                             # only the pair (0, D-1) is correlated
+    assert abs(err[0, 0] - 5e5) / 5e5 < 1e-3 and abs(err[99, 99] - 5e5) / 5e5 < 1e-3
+    assert abs(err[0, 99] + 5e5) / 5e5 < 1e-3
+    inner = err[1:99, 1:99]
+    assert np.allclose(inner, np.eye(98), atol=1e-12)
+    assert np.allclose(cov @ err, np.eye(100), atol=1e-6)
+
+
+def test_cholesky_restatement(oracle):
+    rng = np.random.default_rng(5)
+    a = rng.standard_normal((12, 12))
+    spd = a @ a.T + 12 * np.eye(12)
+    ok, u = oracle.cholesky(spd)
+    assert ok and np.allclose(u.T @ u, spd, rtol=1e-13) and np.array_equal(u, np.triu(u))
+    assert np.allclose(u, np.linalg.cholesky(spd).T, rtol=1e-12)
+    bad = spd.copy(); bad[3, 3] = -1.0
+    assert not oracle.cholesky(bad)[0]
+    nanm = spd.copy(); nanm[2, 5] = nanm[5, 2] = np.nan
+    assert not oracle.cholesky(nanm)[0]
+
+
+def test_eigen_restatement(oracle):
+    rng = np.random.default_rng(6)
+    a = rng.standard_normal((9, 9)); s = a + a.T
+    val, vec = oracle.eigen(s)
+    assert np.all(np.diff(val) <= 0)                 # descending, as TSimpleMCMC.H:1287 assumes
+    assert np.allclose(vec @ np.diag(val) @ vec.T, s, atol=1e-12)
+    assert np.allclose(np.sort(val), np.linalg.eigvalsh(s), atol=1e-12)
+
+
+def test_update_proposal_ladder(oracle):
+    # conditioning path: a correlation hint at the clamp (SimpleMCMC.C:107-115 injects 1.0/0.0)
+    c = oracle.Chain(4)
+    c.set_correlation(2, 3, np.inf)
+    assert c.start(np.zeros(4))
+    cov = c.covariance
+    max_corr = 1.0 - np.sqrt(np.finfo(float).eps)
+    assert cov[2, 3] == max_corr and cov[3, 2] == max_corr      # clamped in SetCorrelation (:897-902)
+    u = c.decomposition
+    assert np.allclose(u.T @ u, cov, rtol=1e-12)
+    # user hints that cannot be decomposed even after the ladder: the reference throws
+    d = oracle.Chain(3)
+    d.set_correlation(0, 1, 0.99); d.set_correlation(1, 2, 0.99); d.set_correlation(0, 2, -0.99)
+    d.start(np.zeros(3))
+    s = d.scalars
+    assert s["last_update_path"] in (2.0, 3.0) or s["failed"] == 1.0   # eigen fallback / emergency shrink / throw
+    if s["last_update_path"] == 2.0:
+        assert np.isfinite(d.decomposition).all()
+
+
+def test_posterior_iso_gaussian(oracle):
+    dim, n = 5, 1_000_000
+    c = oracle.Chain(dim)
+    c.start(np.zeros(dim))
+    c.run_quiet(20000)
+    s, ss, nacc = c.run_moments(n)
+    mean = s / n
+    cov = ss / n - np.outer(mean, mean)
+    assert np.max(np.abs(mean)) < 0.05
+    assert np.max(np.abs(cov - np.eye(dim))) < 0.08
+    assert 0.15 < nacc / n < 0.35                    # target 0.234 (TSimpleMCMC.H:1709)
+
+
+def test_posterior_correlated_gaussian_example4_shape(oracle):
+    """The closed-form known answer of example4 (TConstrainedLikelihood.H:26-110): a
+    Gaussian whose precision is diag(1/s_i^2) + 1 1^T / 16^2.  Centred at zero here;
+    the posterior covariance is the inverse precision."""
+    dim = 8
+    s = np.array([6.08] * (dim - 1) + [2.0])
+    prec = np.diag(1.0 / s ** 2) + np.ones((dim, dim)) / 16.0 ** 2
+    c = oracle.Chain(dim, kind=oracle.LIKE_QUADFORM, params=prec)
+    for i in range(dim):
+        c.set_gaussian(i, s[i])
+    c.start(np.zeros(dim))
+    c.run_quiet(100000)
+    n = 1_500_000
+    sm, ss, _ = c.run_moments(n)
+    cov = ss / n - np.outer(sm / n, sm / n)
+    want = np.linalg.inv(prec)
+    assert np.max(np.abs(cov - want) / np.sqrt(np.outer(np.diag(want), np.diag(want)))) < 0.08
+
+
+def test_simplemcmc_schedule_config1(oracle):
+    """BASELINE config 1: the SimpleMCMC.C:163-256 schedule (burn-in, ResetProposal,
+    4 saved burn-in cycles with UpdateProposal, then cycles x steps) at D=5."""
+    dim, cycles, steps = 5, 10, 20000
+    c = oracle.Chain(dim)
+    c.start(np.zeros(dim))
+    awin = min(max(int(0.1 * steps), 100), 1000)
+    c.set_acceptance_window(float(awin)); c.set_covariance_window(steps)
+    c.run_quiet(steps)
+    c.reset_proposal()
+    c.set_acceptance_window(float(awin)); c.set_covariance_window(2 * steps); c.set_covariance_deweight(0.5)
+    for _ in range(4):
+        c.run_quiet(steps)
+        c.update_proposal()
+    c.set_acceptance_window(1000.0); c.set_acceptance_rigidity(2.0)
+    c.set_covariance_window(cycles * steps); c.set_covariance_deweight(0.20); c.set_next_update(1e9)
+    for _ in range(cycles):
+        c.run_quiet(steps)
+        c.update_proposal()
+        c.set_acceptance_rigidity(2.0); c.set_covariance_deweight(0.0); c.set_next_update(10.0 * steps)
+    s = c.scalars
+    assert s["failed"] == 0 and s["total_steps"] == (5 + cycles) * steps
+    assert 0.18 < s["acceptance"] < 0.30
+    assert np.max(np.abs(c.covariance - np.eye(dim))) < 0.15
+    assert np.max(np.abs(c.center)) < 0.1
+
+
+def test_seed_and_chain_id_select_the_stream(oracle):
+    def run(seed, cid):
+        c = oracle.Chain(6, seed=seed, chain_id=cid)
+        c.start(np.zeros(6)); c.run_quiet(500)
+        return c.accepted
+    assert np.array_equal(run(3, 0), run(3, 0))
+    assert not np.array_equal(run(3, 0), run(4, 0))
+    assert not np.array_equal(run(3, 0), run(3, 1))
+
+
+def test_debug_modes(oracle):
+    c = oracle.Chain(4)
+    c.start(np.full(4, 2.0))
+    out = c.run(300, metropolis=1)                   # only uphill steps (TSimpleMCMC.H:365-366, 448)
+    assert np.all(np.diff(out["logl_accepted"]) >= 0)
+    d = oracle.Chain(4)
+    d.start(np.zeros(4))
+    out = d.run(50, metropolis=2)                    # accept everything (:368, 414-426)
+    assert out["accepted"].all()
+    e = oracle.Chain(4)
+    e.start(np.zeros(4))
+    e.force_step(np.array([0.1, 0.2, 0.3, 0.4]))     # ForceStep (:811-817, 671-678)
+    assert e.step(metropolis=2)
+    assert np.array_equal(e.accepted, [0.1, 0.2, 0.3, 0.4]) and e.scalars["trials"] == 0
+    f = oracle.Chain(4)
+    f.start(np.zeros(4)); f.set_scan_dimension(2)    # scan (:685-704): only dimension 2 moves
+    f.step(metropolis=2)
+    x = f.accepted
+    assert x[0] == 0 and x[1] == 0 and x[3] == 0 and x[2] != 0

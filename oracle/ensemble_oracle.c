@@ -19,8 +19,9 @@
  * y[D] = 1, each group keeps acc[i][j] (0 <= j <= i <= D) and folds one chain
  * after another, one step after another, with a fused multiply-add:
  *     acc[i][j] = fma(y_k[i], y_k[j], acc[i][j]),  k = 0..63 ascending.
- * Group sums are added in group order.  This is the order the wave-level
- * v_mfma_f64_16x16x4_f64 accumulation produces on the GPU.
+ * Group sums are added in group order within chunks of 32 groups, chunk sums in
+ * chunk order.  This is the order the wave-level v_mfma_f64_16x16x4_f64
+ * accumulation and the two-level reduction kernels produce on the GPU.
  */
 #include "oracle_core.h"
 
@@ -321,14 +322,21 @@ void oracle_ensemble_step(oracle_ensemble* e, int nsteps, int metropolis) {
     for (int s = 0; s < nsteps; ++s) ens_step_once(e, metropolis);
 }
 
-/* Sum the group accumulators in group order into moments[(D+1)(D+2)/2] and
- * clear them. */
+/* Sum the group accumulators into moments[(D+1)(D+2)/2] and clear them.  Two
+ * ordered levels, as the HIP reduction does it: groups in ascending order within
+ * chunks of 32 groups, then the chunk sums in ascending order. */
+#define ENS_REDUCE_CHUNK 32
 void oracle_ensemble_reduce_moments(oracle_ensemble* e, double* moments) {
     const int npk = ens_npacked(e->dim);
     for (int k = 0; k < npk; ++k) {
-        double s = 0.0;
-        for (int g = 0; g < e->ngroups; ++g) s += e->acc[(size_t)g * (size_t)npk + (size_t)k];
-        moments[k] = s;
+        double total = 0.0;
+        for (int g0 = 0; g0 < e->ngroups; g0 += ENS_REDUCE_CHUNK) {
+            double s = 0.0;
+            for (int g = g0; g < e->ngroups && g < g0 + ENS_REDUCE_CHUNK; ++g)
+                s += e->acc[(size_t)g * (size_t)npk + (size_t)k];
+            total += s;
+        }
+        moments[k] = total;
     }
     memset(e->acc, 0, sizeof(double) * (size_t)e->ngroups * (size_t)npk);
 }

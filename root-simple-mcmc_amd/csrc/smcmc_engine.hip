@@ -43,9 +43,10 @@ hipError_t dispatch_step(int dp, const StepParams& p, int like, bool exact, bool
     }
 }
 
-hipError_t dispatch_reduce(int dp, double* gacc, int ngroups, int D, double* moments, hipStream_t s) {
+hipError_t dispatch_reduce(int dp, double* gacc, int ngroups, int D, double* chunks, double* moments,
+                           hipStream_t s) {
     switch (dp) {
-#define SMCMC_DP_CASE(n) case n: return launch_reduce<n>(gacc, ngroups, D, moments, s);
+#define SMCMC_DP_CASE(n) case n: return launch_reduce<n>(gacc, ngroups, D, chunks, moments, s);
         SMCMC_FOR_EACH_DP(SMCMC_DP_CASE)
 #undef SMCMC_DP_CASE
         default: return hipErrorInvalidValue;
@@ -83,6 +84,7 @@ struct smcmc_engine {
     double* d_c0 = nullptr;
     double* d_gacc = nullptr;
     double* d_moments = nullptr;
+    double* d_chunks = nullptr;
     double* d_forced = nullptr;
     std::string error;
 };
@@ -268,6 +270,7 @@ int smcmc_create(int dim, int nchains, int likelihood, uint64_t seed, uint32_t c
     HIP_TRY(h, hipMalloc(&h->d_c0, sizeof(double) * dp));
     HIP_TRY(h, hipMalloc(&h->d_gacc, sizeof(double) * (size_t)h->ngroups * h->nt * 4 * kWave));
     HIP_TRY(h, hipMalloc(&h->d_moments, sizeof(double) * npacked(h)));
+    HIP_TRY(h, hipMalloc(&h->d_chunks, sizeof(double) * npacked(h) * ((h->ngroups + kReduceChunk - 1) / kReduceChunk)));
     HIP_TRY(h, hipMemset(h->d_x, 0, sizeof(double) * np * dp));
     HIP_TRY(h, hipMemset(h->d_forced, 0, sizeof(double) * np * dp));
     HIP_TRY(h, hipMemset(h->d_lane_f64, 0, sizeof(double) * np * SMCMC_LANE_F64_COUNT_));
@@ -288,7 +291,7 @@ int smcmc_destroy(smcmc_engine* h) {
     }
     (void)hipFree(h->d_x); (void)hipFree(h->d_forced); (void)hipFree(h->d_lane_f64); (void)hipFree(h->d_lane_i32);
     (void)hipFree(h->d_U); (void)hipFree(h->d_like); (void)hipFree(h->d_c0); (void)hipFree(h->d_gacc);
-    (void)hipFree(h->d_moments);
+    (void)hipFree(h->d_moments); (void)hipFree(h->d_chunks);
     delete h->prop;
     delete h;
     return SMCMC_OK;
@@ -527,7 +530,7 @@ int smcmc_moments_size(const smcmc_engine* h) { return h ? (int)npacked(h) : 0; 
 
 int smcmc_reduce_moments(smcmc_engine* h) {
     if (!h || !h->started) return SMCMC_ERR_INVALID;
-    hipError_t e = dispatch_reduce(h->dp, h->d_gacc, h->ngroups, h->dim, h->d_moments, h->stream);
+    hipError_t e = dispatch_reduce(h->dp, h->d_gacc, h->ngroups, h->dim, h->d_chunks, h->d_moments, h->stream);
     if (e != hipSuccess) return fail(h, SMCMC_ERR_HIP, std::string("reduce kernel launch: ") + hipGetErrorString(e));
     HIP_TRY(h, hipMemsetAsync(h->d_gacc, 0, sizeof(double) * (size_t)h->ngroups * h->nt * 4 * kWave, h->stream));
     return SMCMC_OK;

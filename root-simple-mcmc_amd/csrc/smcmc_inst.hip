@@ -27,10 +27,15 @@ hipError_t launch_step_like<SMCMC_DP, SMCMC_LIKE>(const StepParams& p, bool exac
 
 #if SMCMC_LIKE == 0
 template <>
-hipError_t launch_reduce<SMCMC_DP>(double* gacc, int ngroups, int D, double* moments, hipStream_t s) {
+hipError_t launch_reduce<SMCMC_DP>(double* gacc, int ngroups, int D, double* chunk_sums, double* moments,
+                                   hipStream_t s) {
     const int npk = (D + 1) * (D + 2) / 2;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(reduce_moments_kernel<SMCMC_DP>), dim3((npk + 255) / 256), dim3(256), 0, s,
-                       gacc, ngroups, D, moments);
+    const int nchunks = (ngroups + kReduceChunk - 1) / kReduceChunk;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(reduce_chunks_kernel<SMCMC_DP>), dim3((npk + 63) / 64, nchunks), dim3(64), 0, s,
+                       gacc, ngroups, D, chunk_sums);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(reduce_final_kernel<SMCMC_DP>), dim3((npk + 63) / 64), dim3(64), 0, s, chunk_sums, nchunks, npk, moments);
     return hipGetLastError();
 }
 #endif

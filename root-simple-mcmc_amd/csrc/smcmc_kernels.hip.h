@@ -109,6 +109,12 @@ struct UPieces {
         return n;
     }
     static constexpr int COUNT = count();
+    // pieces of the blocks before B (all rows < 4B)
+    static constexpr int first_global() {
+        int n = 0;
+        for (int i = 0; i < 4 * B; ++i) n += per_row(i);
+        return n;
+    }
     static constexpr int row(int r) {
         int i = 4 * B;
         while (r >= per_row(i)) { r -= per_row(i); ++i; }
@@ -130,6 +136,13 @@ __device__ __forceinline__ void load_piece(lds_cptr_f64 up, f64x2 (&dst)[kPiece 
         if (c + 2 * k < UL::DPE)
             dst[k] = *(volatile lds_cptr_f64x2)(up + UL::off(i) + (c - UL::j0(i)) + 2 * k);
     }
+}
+
+// row ti of lower-triangular tile number `tile` (tile = ti (ti + 1) / 2 + tj, tj <= ti)
+constexpr int tile_row(int tile) {
+    int ti = 0;
+    while ((ti + 1) * (ti + 2) / 2 <= tile) ++ti;
+    return ti;
 }
 
 struct StepParams {
@@ -416,30 +429,9 @@ __global__ void __launch_bounds__(kWave, 2) step_kernel(const StepParams p) {
         // keeps them inside the step.
         lds_cptr_f64 up = (lds_cptr_f64)us;
         asm volatile("" : "+v"(up));
+        double ma[MOMENTS ? T : 1];   // matrix-pipe operands of the chain quad being folded
         static_for<NB>([&](auto bc) {
             constexpr int b = decltype(bc)::value;
-            if constexpr (MOMENTS) {
-                // the group's second moments: the 64-chain contraction is cut into chunks
-                // spread over the Philox blocks so the matrix pipe runs under the VALU work;
-                // chains are folded in ascending order (kk ascending across b)
-#pragma unroll
-                for (int kk = 0; kk < 16; ++kk) {
-                    if (kk < (16 * b) / NB || kk >= (16 * (b + 1)) / NB) continue;
-                    double a[T];
-#pragma unroll
-                    for (int t = 0; t < T; ++t) {
-                        a[t] = xs[xrow[t] + 4 * kk] - c0r[t];
-                        if (16 * t + 15 > DP) a[t] = (16 * t + (lane & 15) <= DP) ? a[t] : 0.0;   // rows past the ones row
-                    }
-#pragma unroll
-                    for (int ti = 0; ti < T; ++ti)
-#pragma unroll
-                        for (int tj = 0; tj < T; ++tj)
-                            if (tj <= ti)
-                                acc[ti * (ti + 1) / 2 + tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(
-                                    a[ti], a[tj], acc[ti * (ti + 1) / 2 + tj], 0, 0, 0);
-                }
-            }
             // U rows 4b..4b+3 are consumed in pieces of kPiece columns; the LDS reads of a
             // piece are issued one piece ahead of its use (the first one before the random
             // numbers are made), and each piece is its own scheduling region: the scheduler
@@ -483,6 +475,30 @@ __global__ void __launch_bounds__(kWave, 2) step_kernel(const StepParams p) {
                         asm volatile("" : "+v"(xp[j]));
                     }
                 }
+                if constexpr (MOMENTS) {
+                    // The group's second moments: the 16 x NT matrix instructions of the 64-chain
+                    // contraction are dealt out over the pieces of the step (1-2 per piece), so
+                    // each one runs on the matrix pipe under the piece's VALU work instead of
+                    // stalling the wavefront back to back.  Chains fold in ascending order.
+                    constexpr int g = PC::first_global() + r;          // piece number within the step
+                    constexpr int G = UPieces<DP, FULLU, NB - 1>::first_global() + UPieces<DP, FULLU, NB - 1>::COUNT;
+                    constexpr int NM = 16 * NT;
+                    constexpr int m_lo = (int)(((long)g * NM) / G), m_hi = (int)(((long)(g + 1) * NM) / G);
+                    static_for<m_hi - m_lo>([&](auto mc) {
+                        constexpr int m = m_lo + decltype(mc)::value;
+                        constexpr int kk = m / NT, tile = m % NT;
+                        if constexpr (tile == 0) {
+#pragma unroll
+                            for (int t = 0; t < T; ++t) {
+                                ma[t] = xs[xrow[t] + 4 * kk] - c0r[t];
+                                if (16 * t + 15 > DP) ma[t] = (16 * t + (lane & 15) <= DP) ? ma[t] : 0.0;   // rows past the ones row
+                            }
+                        }
+                        constexpr int ti = tile_row(tile), tj = tile - ti * (ti + 1) / 2;
+                        acc[tile] = __builtin_amdgcn_mfma_f64_16x16x4f64(ma[ti], ma[tj], acc[tile], 0, 0, 0);
+                        asm volatile("" : "+a"(acc[tile]));   // keeps the instruction in this piece
+                    });
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (r + 1 < PC::COUNT) {
 #pragma unroll
@@ -525,16 +541,14 @@ __global__ void __launch_bounds__(kWave, 2) step_kernel(const StepParams p) {
     }
 }
 
-// Sums the per-group accumulator tiles in group order into the packed moment
-// vector M[(D+1)(D+2)/2].  One thread per packed element.
+// Moment reduction, two ordered levels (the order is part of the engine's definition and
+// is mirrored by oracle/ensemble_oracle.c): groups are summed in ascending order within
+// chunks of kReduceChunk groups, then the chunk sums in ascending order.
+constexpr int kReduceChunk = 32;
+
+// offset of packed element k = (i, j), j <= i <= D, inside one group's tiles
 template <int DP>
-__global__ void reduce_moments_kernel(const double* __restrict__ gacc, int ngroups, int D,
-                                      double* __restrict__ moments) {
-    constexpr int NT = Geo<DP>::NT;
-    const int npk = (D + 1) * (D + 2) / 2;
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= npk) return;
-    // unpack k -> (i, j), j <= i
+__device__ __forceinline__ size_t packed_to_tile_offset(int k, int D) {
     int i = (int)((__builtin_sqrt(8.0 * (double)k + 1.0) - 1.0) * 0.5);
     while ((i + 1) * (i + 2) / 2 <= k) ++i;
     while (i * (i + 1) / 2 > k) --i;
@@ -544,17 +558,48 @@ __global__ void reduce_moments_kernel(const double* __restrict__ gacc, int ngrou
     // C/D layout of v_mfma_f64_16x16x4_f64: column = lane & 15, row = (lane >> 4) + 4*reg
     const int reg = ii >> 2;
     const int lane = jj + 16 * (ii & 3);
-    const size_t off = ((size_t)(ti * (ti + 1) / 2 + tj) * 4 + reg) * kWave + lane;
+    return ((size_t)(ti * (ti + 1) / 2 + tj) * 4 + reg) * kWave + lane;
+}
+
+// level 1: thread (k, chunk) -> chunk_sums[chunk][k]
+template <int DP>
+__global__ void reduce_chunks_kernel(const double* __restrict__ gacc, int ngroups, int D,
+                                     double* __restrict__ chunk_sums) {
+    constexpr int NT = Geo<DP>::NT;
+    const int npk = (D + 1) * (D + 2) / 2;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const int chunk = blockIdx.y;
+    if (k >= npk) return;
+    const size_t off = packed_to_tile_offset<DP>(k, D);
     const size_t gstride = (size_t)NT * 4 * kWave;
+    const int g0 = chunk * kReduceChunk;
+    const int g1 = (g0 + kReduceChunk < ngroups) ? g0 + kReduceChunk : ngroups;
+    double v[kReduceChunk];
+#pragma unroll
+    for (int q = 0; q < kReduceChunk; ++q) v[q] = (g0 + q < g1) ? gacc[(size_t)(g0 + q) * gstride + off] : 0.0;
     double s = 0.0;
-    for (int g = 0; g < ngroups; ++g) s += gacc[(size_t)g * gstride + off];
+#pragma unroll
+    for (int q = 0; q < kReduceChunk; ++q)
+        if (g0 + q < g1) s += v[q];
+    chunk_sums[(size_t)chunk * npk + k] = s;
+}
+
+// level 2: thread k -> moments[k]
+template <int DP>
+__global__ void reduce_final_kernel(const double* __restrict__ chunk_sums, int nchunks, int npk,
+                                    double* __restrict__ moments) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= npk) return;
+    double s = 0.0;
+    for (int c = 0; c < nchunks; ++c) s += chunk_sums[(size_t)c * npk + k];
     moments[k] = s;
 }
 
 // Host-callable launchers, one translation unit per (DP, likelihood) (smcmc_inst.hip).
 template <int DP, int LIKE> hipError_t launch_step_like(const StepParams& p, bool exact, bool fullu, bool moments,
                                                         hipStream_t stream);
-template <int DP> hipError_t launch_reduce(double* gacc, int ngroups, int D, double* moments, hipStream_t stream);
+template <int DP> hipError_t launch_reduce(double* gacc, int ngroups, int D, double* chunk_sums, double* moments,
+                                           hipStream_t stream);
 
 template <int DP>
 inline hipError_t launch_step(const StepParams& p, int like, bool exact, bool fullu, bool moments,

@@ -131,6 +131,14 @@ def main():
     bytes_cs = 16 * dim + 16
     achieved = per_launch * bytes_cs / (kms * 1e-3) / 1e9
 
+    # HBM bytes of one launch from the PMC counters (collected in separate rocprofv3 passes,
+    # profiles/r01_pmc_traffic.json); only valid for the configuration it was measured on
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if (os.path.exists(pmc) and dim == DIM and args.chains == CHAINS_PER_GPU and args.window == WINDOW
+            and not args.fast and not args.frozen):
+        traffic = json.load(open(pmc))["hbm_bytes_per_launch"]
+
     naccept = eng.lane("naccept").astype(np.float64)
     total_steps = eng.get_param("TOTAL_STEPS")
     out = {
@@ -145,7 +153,9 @@ def main():
         "accept_rate": float(naccept.sum() / (total_steps * args.chains)),
         "mean_sigma": float(eng.lane("sigma").mean()),
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                     "traffic_unit": "bytes per launch (2 x FETCH_SIZE + WRITE_SIZE)",
+                     "algorithmic_bytes_per_launch": per_launch * bytes_cs,
                      "kernel": "step_kernel<50,ISO,%s,tri,moments>" % ("fused" if args.fast else "exact"),
                      "kernel_ms": kms, "bytes_per_chain_step": bytes_cs,
                      "chain_steps_per_launch": per_launch},

@@ -113,7 +113,8 @@ const char* smcmc_last_error(const smcmc_engine* h);
 const char* smcmc_status_string(int status);
 /* Build facts, callable without a GPU: library version, compiled kernel families. */
 int smcmc_version(void);
-int smcmc_max_register_dim(void);
+int smcmc_max_register_dim(void);   /* largest dim of the register-resident kernels (63) */
+int smcmc_max_dim(void);            /* largest dim any kernel covers (512) */
 /* hipStream_t to launch on (NULL = default stream). */
 int smcmc_set_stream(smcmc_engine* h, void* hip_stream);
 

@@ -190,6 +190,7 @@ int oracle_ensemble_start(oracle_ensemble* e, const double* x0, int broadcast) {
         e->trials[c] = 0; e->successes[c] = 0;
         e->next_update[c] = e->prop.next_update;
         e->last_value[c] = e->logl[c];
+        e->last_logl_proposed[c] = e->logl[c];   /* fProposedLogLikelihood = L(start), TSimpleMCMC.H:258 */
         e->last_x0[c] = e->x[c];
         e->step_rms[c] = 0.0; e->step_rms_trials[c] = 0; e->naccept[c] = 0;
     }

@@ -38,6 +38,7 @@ SIGNATURES = {
     "smcmc_status_string": (C.c_char_p, [C.c_int]),
     "smcmc_version": (C.c_int, []),
     "smcmc_max_register_dim": (C.c_int, []),
+    "smcmc_max_dim": (C.c_int, []),
     "smcmc_set_stream": (C.c_int, [_H, C.c_void_p]),
     "smcmc_set_likelihood_params": (C.c_int, [_H, _dp, C.c_int]),
     "smcmc_set_mode": (C.c_int, [_H, C.c_int]),

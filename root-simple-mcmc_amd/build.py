@@ -46,6 +46,8 @@ def _units():
     for dp in dp_list():
         for like in LIKELIHOODS:
             units.append(("smcmc_inst.hip", [f"-DSMCMC_DP={dp}", f"-DSMCMC_LIKE={like}"], f"inst_dp{dp}_l{like}"))
+    for w in (4, 8):
+        units.append(("smcmc_panel_inst.hip", [f"-DSMCMC_PANEL_W={w}"], f"panel_w{w}"))
     return units
 
 

@@ -15,6 +15,7 @@
 
 #include "smcmc.h"
 #include "smcmc_kernels.hip.h"
+#include "smcmc_panel_kernel.hip.h"
 #include "smcmc_proposal.hpp"
 
 using namespace smcmc;
@@ -62,6 +63,7 @@ int tiles_for(int dp) {
 
 struct smcmc_engine {
     int dim = 0, nchains = 0, npad = 0, ngroups = 0, dp = 0, nt = 0;
+    int panel_w = 0;   // 0: register-resident kernels (dim <= 63); 4 / 8: wavefronts per chain group of the panel kernel
     int likelihood = 0, mode = SMCMC_MODE_POOLED, device = 0;
     bool exact = true, started = false;
     uint64_t seed = 0;
@@ -129,6 +131,20 @@ int upload_padded(smcmc_engine* h, const double* src, double* dst_dev) {
 }
 
 int upload_shared(smcmc_engine* h) {
+    if (h->panel_w) {
+        // Uperm[w][i][jl] = U(i, jl*W + w): every wavefront's columns contiguous per row
+        const int D = h->dim, W = h->panel_w;
+        std::vector<double> perm((size_t)W * D * kPanelCW, 0.0);
+        for (int w = 0; w < W; ++w)
+            for (int i = 0; i < D; ++i)
+                for (int jl = 0; jl < kPanelCW; ++jl) {
+                    const int j = jl * W + w;
+                    if (j < D) perm[((size_t)w * D + i) * kPanelCW + jl] = h->prop->decomp[(size_t)i * D + j];
+                }
+        HIP_TRY(h, hipMemcpyAsync(h->d_U, perm.data(), perm.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        return SMCMC_OK;
+    }
     int st = upload_padded(h, h->prop->decomp.data(), h->d_U);
     if (st) return st;
     std::vector<double> c0(h->dp, 0.0);
@@ -203,6 +219,29 @@ int launch(smcmc_engine* h, int nsteps, int metropolis, int stride, double* save
         if (stride <= 0) return fail(h, SMCMC_ERR_INVALID, "save stride must be positive");
         p.save_x = save_x; p.save_logl = save_logl; p.save_stride = stride;
     }
+    if (h->panel_w) {
+        if (h->mode == SMCMC_MODE_POOLED)
+            return fail(h, SMCMC_ERR_UNSUPPORTED, "pooled covariance for dim > 63 is not on the HIP path yet");
+        PanelParams q;
+        std::memset(&q, 0, sizeof(q));
+        q.nchains = p.nchains; q.npad = p.npad; q.dim = p.dim; q.nsteps = p.nsteps; q.metropolis = p.metropolis;
+        q.step0 = p.step0; q.chain_offset = p.chain_offset; q.seed = p.seed;
+        q.Uperm = h->d_U; q.like = h->d_like;
+        q.target = p.target; q.acc_window = p.acc_window; q.asig = p.asig; q.max_up = p.max_up;
+        q.acc_w = p.acc_w; q.acc_wW = p.acc_wW; q.pending_sigma_scale = p.pending_sigma_scale;
+        q.pending_deweight = p.pending_deweight; q.per_lane_update = p.per_lane_update;
+        q.step_rms_window = p.step_rms_window; q.full_u = h->prop->decompFull ? 1 : 0;
+        q.x = p.x; q.lane_f64 = p.lane_f64; q.lane_i32 = p.lane_i32;
+        q.save_x = p.save_x; q.save_logl = p.save_logl; q.save_stride = p.save_stride;
+        const bool exact = h->exact || h->prop->decompFull;
+        hipError_t e = (h->panel_w == 4) ? launch_panel<4, kPanelCW>(q, h->likelihood, exact, h->stream)
+                                         : launch_panel<8, kPanelCW>(q, h->likelihood, exact, h->stream);
+        if (e != hipSuccess) return fail(h, SMCMC_ERR_HIP, std::string("panel kernel launch: ") + hipGetErrorString(e));
+        h->total_steps += (uint32_t)nsteps;
+        h->pending_sigma_scale = 1.0;
+        h->pending_deweight = 0;
+        return SMCMC_OK;
+    }
     const bool moments = (h->mode == SMCMC_MODE_POOLED);
     const bool fullu = h->prop->decompFull;
     const bool exact = h->exact || fullu;   // the full (eigen) decomposition only exists in reference order
@@ -221,6 +260,7 @@ extern "C" {
 
 int smcmc_version(void) { return 100; }
 int smcmc_max_register_dim(void) { return kDPList[kNumDP - 1]; }
+int smcmc_max_dim(void) { return 8 * kPanelCW; }
 
 const char* smcmc_status_string(int status) {
     switch (status) {
@@ -248,24 +288,34 @@ int smcmc_create(int dim, int nchains, int likelihood, uint64_t seed, uint32_t c
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return SMCMC_ERR_NO_DEVICE;
     if (device < 0 || device >= ndev) return SMCMC_ERR_NO_DEVICE;
-    const int dp = pick_dp(dim);
-    if (dp < 0) return SMCMC_ERR_UNSUPPORTED;
+    int dp = pick_dp(dim);
+    int panel_w = 0;
+    if (dp < 0) {
+        // large dimensions: a workgroup of 4 or 8 wavefronts per 64-chain group (smcmc_panel_kernel.hip.h)
+        if (dim <= 4 * kPanelCW) panel_w = 4;
+        else if (dim <= 8 * kPanelCW) panel_w = 8;
+        else return SMCMC_ERR_UNSUPPORTED;
+        if (likelihood == SMCMC_LIKE_QUADFORM) return SMCMC_ERR_UNSUPPORTED;
+        dp = dim;
+    }
     smcmc_engine* h = new (std::nothrow) smcmc_engine();
     if (!h) return SMCMC_ERR_RUNTIME;
     h->dim = dim; h->nchains = nchains; h->likelihood = likelihood; h->seed = seed;
-    h->chain_offset = chain_offset; h->device = device; h->dp = dp;
+    h->chain_offset = chain_offset; h->device = device; h->dp = dp; h->panel_w = panel_w;
     h->npad = (nchains + kWave - 1) / kWave * kWave;
     h->ngroups = h->npad / kWave;
-    h->nt = tiles_for(dp);
+    h->nt = panel_w ? 1 : tiles_for(dp);
     h->prop = new SharedProposal(dim);
     *out = h;
     HIP_TRY(h, hipSetDevice(device));
     const size_t np = (size_t)h->npad;
+    const size_t u_doubles = panel_w ? (size_t)panel_w * dim * kPanelCW : (size_t)dp * dp;
     HIP_TRY(h, hipMalloc(&h->d_x, sizeof(double) * np * dp));        // rows >= dim stay zero
     HIP_TRY(h, hipMalloc(&h->d_forced, sizeof(double) * np * dp));
     HIP_TRY(h, hipMalloc(&h->d_lane_f64, sizeof(double) * np * SMCMC_LANE_F64_COUNT_));
     HIP_TRY(h, hipMalloc(&h->d_lane_i32, sizeof(int32_t) * np * SMCMC_LANE_I32_COUNT_));
-    HIP_TRY(h, hipMalloc(&h->d_U, sizeof(double) * dp * dp));
+    HIP_TRY(h, hipMalloc(&h->d_U, sizeof(double) * u_doubles));
+    HIP_TRY(h, hipMemset(h->d_U, 0, sizeof(double) * u_doubles));
     HIP_TRY(h, hipMalloc(&h->d_like, sizeof(double) * dp * dp));
     HIP_TRY(h, hipMalloc(&h->d_c0, sizeof(double) * dp));
     HIP_TRY(h, hipMalloc(&h->d_gacc, sizeof(double) * (size_t)h->ngroups * h->nt * 4 * kWave));
@@ -275,7 +325,6 @@ int smcmc_create(int dim, int nchains, int likelihood, uint64_t seed, uint32_t c
     HIP_TRY(h, hipMemset(h->d_forced, 0, sizeof(double) * np * dp));
     HIP_TRY(h, hipMemset(h->d_lane_f64, 0, sizeof(double) * np * SMCMC_LANE_F64_COUNT_));
     HIP_TRY(h, hipMemset(h->d_lane_i32, 0, sizeof(int32_t) * np * SMCMC_LANE_I32_COUNT_));
-    HIP_TRY(h, hipMemset(h->d_U, 0, sizeof(double) * dp * dp));
     HIP_TRY(h, hipMemset(h->d_like, 0, sizeof(double) * dp * dp));
     HIP_TRY(h, hipMemset(h->d_c0, 0, sizeof(double) * dp));
     HIP_TRY(h, hipMemset(h->d_gacc, 0, sizeof(double) * (size_t)h->ngroups * h->nt * 4 * kWave));
@@ -446,7 +495,11 @@ int smcmc_start(smcmc_engine* h, const double* x0, int broadcast) {
     HIP_TRY(h, hipMemsetAsync(h->d_lane_f64, 0, sizeof(double) * NP * SMCMC_LANE_F64_COUNT_, h->stream));
     HIP_TRY(h, hipMemsetAsync(h->d_lane_i32, 0, sizeof(int32_t) * NP * SMCMC_LANE_I32_COUNT_, h->stream));
     HIP_TRY(h, hipMemsetAsync(h->d_gacc, 0, sizeof(double) * (size_t)h->ngroups * h->nt * 4 * kWave, h->stream));
-    {
+    if (h->panel_w) {
+        hipError_t e = launch_start_loglike(h->d_x, N, NP, D, h->d_like, h->d_lane_f64 + (size_t)SMCMC_LANE_LOGL * NP,
+                                            h->likelihood, h->exact, h->stream);
+        if (e != hipSuccess) return fail(h, SMCMC_ERR_HIP, std::string("start kernel launch: ") + hipGetErrorString(e));
+    } else {
         StepParams p;
         std::memset(&p, 0, sizeof(p));
         p.nchains = N; p.npad = h->npad; p.dim = D; p.nsteps = 1; p.metropolis = 2;
@@ -515,6 +568,7 @@ int smcmc_step_save(smcmc_engine* h, int nsteps, int metropolis, int stride, dou
 
 int smcmc_force_step(smcmc_engine* h, const double* point, int broadcast) {
     if (!h || !point) return SMCMC_ERR_INVALID;
+    if (h->panel_w) return fail(h, SMCMC_ERR_UNSUPPORTED, "ForceStep for dim > 63 is not on the HIP path yet");
     const int D = h->dim, N = h->nchains;
     const size_t NP = (size_t)h->npad;
     std::vector<double> x(NP * h->dp, 0.0);
@@ -530,6 +584,7 @@ int smcmc_moments_size(const smcmc_engine* h) { return h ? (int)npacked(h) : 0; 
 
 int smcmc_reduce_moments(smcmc_engine* h) {
     if (!h || !h->started) return SMCMC_ERR_INVALID;
+    if (h->panel_w) return fail(h, SMCMC_ERR_UNSUPPORTED, "pooled covariance for dim > 63 is not on the HIP path yet");
     hipError_t e = dispatch_reduce(h->dp, h->d_gacc, h->ngroups, h->dim, h->d_chunks, h->d_moments, h->stream);
     if (e != hipSuccess) return fail(h, SMCMC_ERR_HIP, std::string("reduce kernel launch: ") + hipGetErrorString(e));
     HIP_TRY(h, hipMemsetAsync(h->d_gacc, 0, sizeof(double) * (size_t)h->ngroups * h->nt * 4 * kWave, h->stream));

@@ -1,0 +1,49 @@
+// smcmc_panel_inst.hip -- instantiations of the large-dimension step kernel for one
+// workgroup shape; built once per -DSMCMC_PANEL_W=<wavefronts per chain group>.
+#include "smcmc_panel_kernel.hip.h"
+
+#ifndef SMCMC_PANEL_W
+#error "compile with -DSMCMC_PANEL_W=<4|8>"
+#endif
+
+namespace smcmc {
+
+template <int W, int CW, int LIKE, bool EXACT>
+static hipError_t go_panel(const PanelParams& p, hipStream_t s) {
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(panel_step_kernel<W, CW, LIKE, EXACT>), dim3(p.npad / kWave),
+                       dim3(W * kWave), 0, s, p);
+    return hipGetLastError();
+}
+
+template <>
+hipError_t launch_panel<SMCMC_PANEL_W, kPanelCW>(const PanelParams& p, int like, bool exact, hipStream_t s) {
+    constexpr int W = SMCMC_PANEL_W, CW = kPanelCW;
+    switch (like) {
+        case SMCMC_LIKE_ISO_GAUSS:
+            return exact ? go_panel<W, CW, SMCMC_LIKE_ISO_GAUSS, true>(p, s)
+                         : go_panel<W, CW, SMCMC_LIKE_ISO_GAUSS, false>(p, s);
+        case SMCMC_LIKE_ROSENBROCK:
+            return exact ? go_panel<W, CW, SMCMC_LIKE_ROSENBROCK, true>(p, s)
+                         : go_panel<W, CW, SMCMC_LIKE_ROSENBROCK, false>(p, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+#if SMCMC_PANEL_W == 4
+hipError_t launch_start_loglike(const double* x, int nchains, size_t npad, int D, const double* like_params,
+                                double* logl_out, int like, bool exact, hipStream_t s) {
+    const dim3 grid((nchains + 255) / 256), block(256);
+    if (like == SMCMC_LIKE_ISO_GAUSS) {
+        if (exact) hipLaunchKernelGGL(HIP_KERNEL_NAME(start_loglike_kernel<SMCMC_LIKE_ISO_GAUSS, true>), grid, block, 0, s, x, nchains, npad, D, like_params, logl_out);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(start_loglike_kernel<SMCMC_LIKE_ISO_GAUSS, false>), grid, block, 0, s, x, nchains, npad, D, like_params, logl_out);
+    } else if (like == SMCMC_LIKE_ROSENBROCK) {
+        if (exact) hipLaunchKernelGGL(HIP_KERNEL_NAME(start_loglike_kernel<SMCMC_LIKE_ROSENBROCK, true>), grid, block, 0, s, x, nchains, npad, D, like_params, logl_out);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(start_loglike_kernel<SMCMC_LIKE_ROSENBROCK, false>), grid, block, 0, s, x, nchains, npad, D, like_params, logl_out);
+    } else {
+        return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+#endif
+
+}  // namespace smcmc

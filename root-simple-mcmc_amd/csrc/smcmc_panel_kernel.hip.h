@@ -1,0 +1,354 @@
+// smcmc_panel_kernel.hip.h -- the Metropolis step for dimensions that do not fit one
+// wavefront's registers (63 < D <= W * CW).
+//
+// A workgroup of W wavefronts advances one 64-chain group; lane l of every
+// wavefront is chain l of the group.  Wavefront w owns the proposal columns
+// j = jl * W + w (interleaved, so the triangular work of x' = x + sigma U^T r,
+// reference TSimpleMCMC.H:709-724, is balanced) and keeps them in registers.
+//   - the D normals of a step are generated once, in panels of KP rows, each
+//     wavefront making its share, and handed to the others through LDS
+//   - U is stored per owner, Uperm[w][i][jl] = U(i, jl*W + w), and read with
+//     wave-uniform scalar loads inside a rolled loop over the rows i
+//   - the finished proposal is passed through LDS in panels of kGatherJl local
+//     columns so that wavefront 0 can run StepRMS, the likelihood and the
+//     Metropolis test in the reference's exact summation order
+//     (TSimpleMCMC.H:391-406, 410-463); the verdict goes back through LDS and every
+//     wavefront commits its own columns (:484-491)
+//   - the scalar half of UpdateState (TSimpleMCMC.H:1723-1776) is computed
+//     redundantly by every wavefront (it needs sigma), stored by wavefront 0
+// The accepted point x[dim][chain] stays in HBM and makes the round trip the
+// algorithmic-bytes model of SURVEY.md section 8(d) assumes (16 D + 16 bytes per
+// chain-step).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "smcmc.h"
+#include "smcmc_detmath.h"
+#include "smcmc_kernels.hip.h"
+
+namespace smcmc {
+
+constexpr int kPanelRows = 32;    // rows of normals per LDS panel
+constexpr int kGatherJl = 8;      // local columns per gather panel
+constexpr int kPanelCW = 64;      // proposal columns a wavefront keeps in registers
+
+struct PanelParams {
+    int nchains, npad, dim;
+    int nsteps, metropolis;
+    uint32_t step0, chain_offset;
+    uint64_t seed;
+    const double* Uperm;      // [W][dim][CW]
+    const double* like;       // ROSENBROCK: {b}
+    double target, acc_window, asig, max_up, acc_w, acc_wW, pending_sigma_scale;
+    int pending_deweight, per_lane_update, step_rms_window, full_u;
+    double* x;                // [dim][npad]
+    double* lane_f64;
+    int32_t* lane_i32;
+    double* save_x;           // optional [slot][dim][npad]
+    double* save_logl;
+    int save_stride;
+};
+
+template <int W, int CW, int LIKE, bool EXACT>
+__global__ void __launch_bounds__(W * kWave) panel_step_kernel(const PanelParams p) {
+    __shared__ double rbuf[kPanelRows * kWave];              // normals of the current panel, [row][lane]
+    __shared__ double gp[kGatherJl * W * kWave];             // gathered proposal, [jl][w][lane]
+    __shared__ double gd[kGatherJl * W * kWave];             // gathered trial step x' - x
+    __shared__ double verdict_logl[kWave];
+    __shared__ int verdict_take[kWave];
+
+    const int lane = threadIdx.x & (kWave - 1);
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);   // wave-uniform: lets U go through scalar loads
+    const int group = blockIdx.x;
+    const int chain = group * kWave + lane;
+    const bool active = chain < p.nchains;
+    const int D = p.dim;
+    const size_t NP = (size_t)p.npad;
+    const uint32_t gid = p.chain_offset + (uint32_t)chain;
+    const cptr_f64 Uw = as_const(p.Uperm) + (size_t)w * D * CW;
+    const cptr_f64 likep = as_const(p.like);
+
+    double* lf = p.lane_f64 + chain;
+    int32_t* li = p.lane_i32 + chain;
+    double logl = lf[SMCMC_LANE_LOGL * NP];
+    double sigma = lf[SMCMC_LANE_SIGMA * NP];
+    double acc_rate = lf[SMCMC_LANE_ACCEPTANCE * NP];
+    double acc_trials = lf[SMCMC_LANE_ACCEPTANCE_TRIALS * NP];
+    double rigid = lf[SMCMC_LANE_RIGIDITY * NP];
+    double last_value = lf[SMCMC_LANE_LAST_VALUE * NP];
+    double last_x0 = lf[SMCMC_LANE_LAST_X0 * NP];
+    double step_rms = lf[SMCMC_LANE_STEP_RMS * NP];
+    double logl_prop = lf[SMCMC_LANE_LOGL_PROPOSED * NP];
+    int trials = li[SMCMC_LANE_TRIALS * NP];
+    int succ = li[SMCMC_LANE_SUCCESSES * NP];
+    int next_update = li[SMCMC_LANE_NEXT_UPDATE * NP];
+    int naccept = li[SMCMC_LANE_NACCEPT * NP];
+    int rms_trials = li[SMCMC_LANE_STEP_RMS_TRIALS * NP];
+    int last_accept = li[SMCMC_LANE_LAST_ACCEPT * NP];
+
+    sigma = sigma * p.pending_sigma_scale;
+    if (p.pending_deweight && p.acc_w >= 0.0) {
+        acc_trials = dmax(1.0, p.acc_w * acc_trials);
+        acc_trials = dmin(acc_trials, p.acc_wW);
+    }
+
+    const uint32_t aw = smcmc_accept_word((uint32_t)D);
+    const int npanels = (D + kPanelRows - 1) / kPanelRows;
+    const int ngather = (CW + kGatherJl - 1) / kGatherJl;
+
+    double xp[CW];
+    for (int s = 0; s < p.nsteps; ++s) {
+        const uint64_t step = (uint64_t)(p.step0 + (uint32_t)s + 1u);
+
+        // ---- A: UpdateState, scalar half (TSimpleMCMC.H:1723-1776), every wavefront ----
+        ++trials;
+        const double x0 = p.x[chain];
+        const bool moved = (logl != last_value) || (x0 != last_x0);
+        if (moved) ++succ;
+        acc_rate *= acc_trials;
+        if (moved) acc_rate = acc_rate + 1.0;
+        acc_rate /= acc_trials + 1.0;
+        acc_trials = dmin(p.acc_window, acc_trials + 1.0);
+        if (rigid < 500.0 && rigid > 0.0) {
+            if (__builtin_fabs(acc_rate - p.target) < p.asig) {
+                rigid += 0.5 * rigid / p.acc_window;
+                rigid = dmin(200.0, rigid);
+            }
+            if (__builtin_fabs(acc_rate - p.target) > 4.0 * p.asig) {
+                rigid -= 1.618 * 0.5 * rigid / p.acc_window;
+                rigid = dmax(2.0, rigid);
+            }
+        }
+        if (rigid > 0 && rigid < 100.0) {
+            sigma *= smcmc_pow_small(acc_rate / p.target, dmin(1.0 / 500.0, 1.0 / (rigid * p.acc_window)));
+        }
+        if (p.per_lane_update && moved && (--next_update) < 1) {
+            double up = 0.5 * succ;
+            next_update = (int)(p.acc_window + p.max_up - p.max_up / (up + 1.0));
+            if (p.acc_w >= 0.0) {
+                acc_trials = dmax(1.0, p.acc_w * acc_trials);
+                acc_trials = dmin(acc_trials, p.acc_wW);
+            }
+        }
+        last_value = logl;
+        last_x0 = x0;
+
+        // ---- B: proposal columns of this wavefront ----
+#pragma unroll
+        for (int jl = 0; jl < CW; ++jl) {
+            const int j = jl * W + w;
+            xp[jl] = (j < D) ? p.x[(size_t)j * NP + chain] : 0.0;
+        }
+        uint32_t uword = 0;
+        for (int pn = 0; pn < npanels; ++pn) {
+            const int i0 = pn * kPanelRows;
+            __syncthreads();                       // the previous panel has been consumed
+            // normals of rows i0 .. i0+KP-1: Philox block b covers rows 4b..4b+3
+            for (int bb = w; bb < kPanelRows / 4; bb += W) {
+                const int b = i0 / 4 + bb;
+                if (4 * b < D || (uint32_t)b == (aw >> 2)) {
+                    smcmc_u32x4 blk = smcmc_draw_block(p.seed, gid, step, (uint32_t)b, SMCMC_STREAM_STEP);
+                    if ((uint32_t)b == (aw >> 2)) verdict_logl[lane] = smcmc_u01(smcmc_select_word(blk, aw & 3u));
+                    double n[4];
+                    smcmc_normal_pair(blk.v[0], blk.v[1], &n[0], &n[1]);
+                    smcmc_normal_pair(blk.v[2], blk.v[3], &n[2], &n[3]);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) rbuf[(4 * bb + q) * kWave + lane] = n[q];
+                }
+            }
+            __syncthreads();
+            const int i1 = (i0 + kPanelRows < D) ? i0 + kPanelRows : D;
+            for (int i = i0; i < i1; ++i) {
+                const double sr = sigma * rbuf[(i - i0) * kWave + lane];
+                // first local column with j = jl*W + w >= i (0 for a full matrix)
+                const int jl0 = p.full_u ? 0 : ((i - w + W - 1) / W);
+                const cptr_f64 Urow = Uw + (size_t)i * CW;
+#pragma unroll
+                for (int c = 0; c < CW; c += 16) {
+                    if (c + 15 >= jl0) {
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) {
+                            const double u = Urow[c + k];
+                            if constexpr (EXACT) xp[c + k] += sr * u;
+                            else xp[c + k] = SMCMC_FMA(sr, u, xp[c + k]);
+                        }
+                    }
+                }
+            }
+        }
+        // the Metropolis uniform when its word lies past the last row block
+        if ((aw >> 2) >= (uint32_t)(npanels * (kPanelRows / 4)) && w == 0) {
+            smcmc_u32x4 blk = smcmc_draw_block(p.seed, gid, step, aw >> 2, SMCMC_STREAM_STEP);
+            verdict_logl[lane] = smcmc_u01(smcmc_select_word(blk, aw & 3u));
+        }
+
+        // ---- gather: wavefront 0 walks the proposal in dimension order ----
+        double sqr = 0.0, lsum = 0.0, prev_p = 0.0;
+        const double rb = (LIKE == SMCMC_LIKE_ROSENBROCK) ? likep[0] : 0.0;
+        for (int g = 0; g < ngather; ++g) {
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < kGatherJl; ++q) {
+                const int jl = g * kGatherJl + q;
+                if (jl < CW) {
+                    const int j = jl * W + w;
+                    const double xv = (j < D) ? p.x[(size_t)j * NP + chain] : 0.0;
+                    gp[(q * W + w) * kWave + lane] = xp[jl];
+                    gd[(q * W + w) * kWave + lane] = xp[jl] - xv;
+                }
+            }
+            __syncthreads();
+            if (w == 0) {
+                for (int q = 0; q < kGatherJl; ++q) {
+                    for (int ww = 0; ww < W; ++ww) {
+                        const int j = (g * kGatherJl + q) * W + ww;
+                        if (j < D) {
+                            const double pj = gp[(q * W + ww) * kWave + lane];
+                            const double dj = gd[(q * W + ww) * kWave + lane];
+                            if constexpr (EXACT) sqr += dj * dj;                     // :393-396
+                            else sqr = SMCMC_FMA(dj, dj, sqr);
+                            if constexpr (LIKE == SMCMC_LIKE_ISO_GAUSS) {
+                                const double t = -0.5 * pj;
+                                if constexpr (EXACT) lsum += t * pj;
+                                else lsum = SMCMC_FMA(t, pj, lsum);
+                            } else {
+                                // term i = j-1 of THardLogLikelihood.H:60-64 needs p[j-1] and p[j]
+                                if (j > 0) {
+                                    if constexpr (EXACT) {
+                                        const double a = (1.0 - prev_p);
+                                        const double b = pj - prev_p * prev_p;
+                                        lsum -= a * a + rb * b * b;
+                                    } else {
+                                        const double a = 1.0 - prev_p;
+                                        const double b = SMCMC_FMA(-prev_p, prev_p, pj);
+                                        const double t = SMCMC_FMA(rb * b, b, a * a);
+                                        lsum -= t;
+                                    }
+                                }
+                                prev_p = pj;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+
+        // ---- wavefront 0: StepRMS, Metropolis test (TSimpleMCMC.H:397-463) ----
+        if (w == 0) {
+            if (p.step_rms_window > 0) {
+                double ms = step_rms * step_rms;
+                ms *= rms_trials;
+                ms += sqr;
+                ms /= rms_trials + 1.0;
+                rms_trials = (p.step_rms_window < rms_trials + 1) ? p.step_rms_window : rms_trials + 1;
+                step_rms = __builtin_sqrt(ms);
+            }
+            logl_prop = lsum;
+            bool take;
+            if (p.metropolis == 2) {
+                take = true;
+            } else if (!__builtin_isfinite(logl_prop) || logl_prop < -0.999999E+30) {
+                take = false;
+            } else {
+                const double delta = logl_prop - logl;
+                take = true;
+                if (delta < 0.0) {
+                    if (p.metropolis == 1) take = false;
+                    else {
+                        const double trial = smcmc_log_pos(verdict_logl[lane]);
+                        if (delta < trial) take = false;
+                    }
+                }
+            }
+            take = take && active;
+            verdict_take[lane] = take ? 1 : 0;
+            verdict_logl[lane] = take ? logl_prop : logl;
+        }
+        __syncthreads();
+        const bool take = verdict_take[lane] != 0;
+        const double new_logl = verdict_logl[lane];
+        last_accept = take ? 1 : 0;
+        if (take) ++naccept;
+        logl = new_logl;
+        if (take) {
+#pragma unroll
+            for (int jl = 0; jl < CW; ++jl) {
+                const int j = jl * W + w;
+                if (j < D) p.x[(size_t)j * NP + chain] = xp[jl];
+            }
+        }
+        if (p.save_x != nullptr && ((s + 1) % p.save_stride) == 0 && active) {
+            const size_t slot = (size_t)((s + 1) / p.save_stride - 1);
+#pragma unroll
+            for (int jl = 0; jl < CW; ++jl) {
+                const int j = jl * W + w;
+                if (j < D) p.save_x[(slot * (size_t)D + (size_t)j) * NP + chain] = take ? xp[jl] : p.x[(size_t)j * NP + chain];
+            }
+            if (w == 0) p.save_logl[slot * NP + chain] = logl;
+        }
+        __syncthreads();                           // x is final before the next step reads x[0] / its columns
+    }
+
+    if (active && w == 0) {
+        lf[SMCMC_LANE_LOGL * NP] = logl;
+        lf[SMCMC_LANE_SIGMA * NP] = sigma;
+        lf[SMCMC_LANE_ACCEPTANCE * NP] = acc_rate;
+        lf[SMCMC_LANE_ACCEPTANCE_TRIALS * NP] = acc_trials;
+        lf[SMCMC_LANE_RIGIDITY * NP] = rigid;
+        lf[SMCMC_LANE_LAST_VALUE * NP] = last_value;
+        lf[SMCMC_LANE_LAST_X0 * NP] = last_x0;
+        lf[SMCMC_LANE_STEP_RMS * NP] = step_rms;
+        lf[SMCMC_LANE_LOGL_PROPOSED * NP] = logl_prop;
+        li[SMCMC_LANE_TRIALS * NP] = trials;
+        li[SMCMC_LANE_SUCCESSES * NP] = succ;
+        li[SMCMC_LANE_NEXT_UPDATE * NP] = next_update;
+        li[SMCMC_LANE_NACCEPT * NP] = naccept;
+        li[SMCMC_LANE_STEP_RMS_TRIALS * NP] = rms_trials;
+        li[SMCMC_LANE_LAST_ACCEPT * NP] = last_accept;
+    }
+}
+
+// Start's likelihood call (TSimpleMCMC.H:258) for the large-dimension path: one thread
+// per chain walks its column of x in the reference's summation order.
+template <int LIKE, bool EXACT>
+__global__ void start_loglike_kernel(const double* __restrict__ x, int nchains, size_t npad, int D,
+                                     const double* __restrict__ like, double* __restrict__ logl_out) {
+    const int chain = blockIdx.x * blockDim.x + threadIdx.x;
+    if (chain >= nchains) return;
+    double lsum = 0.0;
+    if constexpr (LIKE == SMCMC_LIKE_ISO_GAUSS) {
+        for (int i = 0; i < D; ++i) {
+            const double pi = x[(size_t)i * npad + chain];
+            const double t = -0.5 * pi;
+            if constexpr (EXACT) lsum += t * pi;
+            else lsum = SMCMC_FMA(t, pi, lsum);
+        }
+    } else {
+        const double rb = like[0];
+        double prev = x[chain];
+        for (int i = 0; i < D - 1; ++i) {
+            const double nx = x[(size_t)(i + 1) * npad + chain];
+            if constexpr (EXACT) {
+                const double a = (1.0 - prev);
+                const double b = nx - prev * prev;
+                lsum -= a * a + rb * b * b;
+            } else {
+                const double a = 1.0 - prev;
+                const double b = SMCMC_FMA(-prev, prev, nx);
+                const double t = SMCMC_FMA(rb * b, b, a * a);
+                lsum -= t;
+            }
+            prev = nx;
+        }
+    }
+    logl_out[chain] = lsum;
+}
+
+template <int W, int CW>
+hipError_t launch_panel(const PanelParams& p, int like, bool exact, hipStream_t stream);
+hipError_t launch_start_loglike(const double* x, int nchains, size_t npad, int D, const double* like_params,
+                                double* logl_out, int like, bool exact, hipStream_t stream);
+
+}  // namespace smcmc

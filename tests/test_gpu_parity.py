@@ -289,3 +289,21 @@ def test_full_size_d50_properties(gpu):
     assert 0.1 < acc < 0.8          # early in the adaptation: sigma still rising toward the 0.234 target
     # the pooled covariance moves toward the target's (identity): trace ~ D
     assert abs(np.trace(a.covariance) / dim - 1.0) < 0.25
+
+
+# ---------------------------------------------------------------- large dimensions (panel kernel)
+@pytest.mark.parametrize("kind,dim,nchains,steps", [(0, 64, 70, 40), (0, 200, 130, 25), (2, 200, 64, 30),
+                                                     (0, 257, 64, 12), (0, 500, 96, 10), (2, 500, 64, 10)])
+@pytest.mark.parametrize("exact", [True, False])
+def test_frozen_large_dim_matches_oracle(gpu, oracle, kind, dim, nchains, steps, exact):
+    """BASELINE configs 3/4 shapes (D=200 Rosenbrock, D=500): a workgroup of 4 or 8
+    wavefronts per 64-chain group, still bit for bit the oracle."""
+    rng = np.random.default_rng(dim + kind)
+    e, o = _pair(gpu, oracle, dim, nchains, kind, gpu.MODE_FROZEN, exact)
+    x0 = _start(kind, dim, nchains, rng)
+    assert e.Start(x0) and o.start(x0)
+    _assert_same_state(e, o, "after start")
+    e.Step(1); o.step(1)
+    _assert_same_state(e, o, "after 1 step")
+    e.Step(steps - 1); o.step(steps - 1)
+    _assert_same_state(e, o, f"after {steps} steps")

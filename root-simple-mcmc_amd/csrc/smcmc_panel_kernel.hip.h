@@ -7,8 +7,9 @@
 // reference TSimpleMCMC.H:709-724, is balanced) and keeps them in registers.
 //   - the D normals of a step are generated once, in panels of KP rows, each
 //     wavefront making its share, and handed to the others through LDS
-//   - U is stored per owner, Uperm[w][i][jl] = U(i, jl*W + w), and read with
-//     wave-uniform scalar loads inside a rolled loop over the rows i
+//   - U is stored per owner, Uperm[w][i][jl] = U(i, jl*W + w); every wavefront copies
+//     its slice of the current row panel into LDS and reads it back with broadcast
+//     128-bit reads inside a rolled loop over the rows i
 //   - the finished proposal is passed through LDS in panels of kGatherJl local
 //     columns so that wavefront 0 can run StepRMS, the likelihood and the
 //     Metropolis test in the reference's exact summation order
@@ -31,7 +32,7 @@
 namespace smcmc {
 
 constexpr int kPanelRows = 32;    // rows of normals per LDS panel
-constexpr int kGatherJl = 8;      // local columns per gather panel
+constexpr int kGatherJl = 16;     // local columns per gather panel
 constexpr int kPanelCW = 64;      // proposal columns a wavefront keeps in registers
 
 struct PanelParams {
@@ -54,20 +55,22 @@ struct PanelParams {
 template <int W, int CW, int LIKE, bool EXACT>
 __global__ void __launch_bounds__(W * kWave) panel_step_kernel(const PanelParams p) {
     __shared__ double rbuf[kPanelRows * kWave];              // normals of the current panel, [row][lane]
-    __shared__ double gp[kGatherJl * W * kWave];             // gathered proposal, [jl][w][lane]
-    __shared__ double gd[kGatherJl * W * kWave];             // gathered trial step x' - x
+    // U panel of every wavefront, [w][row][jl]; after the last panel of a step the same
+    // memory carries the gathered proposal gp[jl][w][lane] and trial step gd = x' - x
+    __shared__ __attribute__((aligned(16))) double ulds[W * kPanelRows * CW];
+    static_assert(2 * kGatherJl * kWave <= kPanelRows * CW, "gather buffers must fit the U staging area");
+    constexpr int kGd = kGatherJl * W * kWave;   // offset of gd inside ulds
     __shared__ double verdict_logl[kWave];
     __shared__ int verdict_take[kWave];
 
     const int lane = threadIdx.x & (kWave - 1);
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);   // wave-uniform: lets U go through scalar loads
+    const int w = threadIdx.x / kWave;
     const int group = blockIdx.x;
     const int chain = group * kWave + lane;
     const bool active = chain < p.nchains;
     const int D = p.dim;
     const size_t NP = (size_t)p.npad;
     const uint32_t gid = p.chain_offset + (uint32_t)chain;
-    const cptr_f64 Uw = as_const(p.Uperm) + (size_t)w * D * CW;
     const cptr_f64 likep = as_const(p.like);
 
     double* lf = p.lane_f64 + chain;
@@ -96,7 +99,7 @@ __global__ void __launch_bounds__(W * kWave) panel_step_kernel(const PanelParams
 
     const uint32_t aw = smcmc_accept_word((uint32_t)D);
     const int npanels = (D + kPanelRows - 1) / kPanelRows;
-    const int ngather = (CW + kGatherJl - 1) / kGatherJl;
+    constexpr int ngather = (CW + kGatherJl - 1) / kGatherJl;
 
     double xp[CW];
     for (int s = 0; s < p.nsteps; ++s) {
@@ -158,26 +161,42 @@ __global__ void __launch_bounds__(W * kWave) panel_step_kernel(const PanelParams
                     for (int q = 0; q < 4; ++q) rbuf[(4 * bb + q) * kWave + lane] = n[q];
                 }
             }
-            __syncthreads();
             const int i1 = (i0 + kPanelRows < D) ? i0 + kPanelRows : D;
+            // this wavefront's slice of the panel, rows i0..i1-1 x CW columns, is contiguous in
+            // Uperm: copy it into the wavefront's LDS area with 16-byte pieces
+            {
+                const f64x2* src = (const f64x2*)(p.Uperm + ((size_t)w * D + i0) * CW);
+                f64x2* dst = (f64x2*)(ulds + w * (kPanelRows * CW));
+                const int npieces = (i1 - i0) * (CW / 2);
+                for (int k = lane; k < npieces; k += kWave) dst[k] = src[k];
+            }
+            __syncthreads();
+            lds_cptr_f64 up = (lds_cptr_f64)(ulds + w * (kPanelRows * CW));
+            asm volatile("" : "+v"(up));   // LDS addresses live in vector registers
             for (int i = i0; i < i1; ++i) {
                 const double sr = sigma * rbuf[(i - i0) * kWave + lane];
                 // first local column with j = jl*W + w >= i (0 for a full matrix)
                 const int jl0 = p.full_u ? 0 : ((i - w + W - 1) / W);
-                const cptr_f64 Urow = Uw + (size_t)i * CW;
+                lds_cptr_f64 urow = up + (i - i0) * CW;
 #pragma unroll
                 for (int c = 0; c < CW; c += 16) {
                     if (c + 15 >= jl0) {
+                        // 16 columns: eight broadcast 128-bit LDS reads, kept next to their use
+                        f64x2 u2[8];
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) u2[k] = *(volatile lds_cptr_f64x2)(urow + c + 2 * k);
 #pragma unroll
                         for (int k = 0; k < 16; ++k) {
-                            const double u = Urow[c + k];
+                            const double u = u2[k / 2][k & 1];
                             if constexpr (EXACT) xp[c + k] += sr * u;
                             else xp[c + k] = SMCMC_FMA(sr, u, xp[c + k]);
+                            asm volatile("" : "+v"(xp[c + k]));
                         }
                     }
                 }
             }
         }
+        __syncthreads();   // the U staging area is reused by the gather below
         // the Metropolis uniform when its word lies past the last row block
         if ((aw >> 2) >= (uint32_t)(npanels * (kPanelRows / 4)) && w == 0) {
             smcmc_u32x4 blk = smcmc_draw_block(p.seed, gid, step, aw >> 2, SMCMC_STREAM_STEP);
@@ -187,26 +206,32 @@ __global__ void __launch_bounds__(W * kWave) panel_step_kernel(const PanelParams
         // ---- gather: wavefront 0 walks the proposal in dimension order ----
         double sqr = 0.0, lsum = 0.0, prev_p = 0.0;
         const double rb = (LIKE == SMCMC_LIKE_ROSENBROCK) ? likep[0] : 0.0;
-        for (int g = 0; g < ngather; ++g) {
-            __syncthreads();
+        // xp[] must be indexed statically to stay in registers: the panel number selects one of
+        // `ngather` fully unrolled write blocks; the (long) serial walk below is emitted once
+        auto write_panel = [&](auto gc) {
+            constexpr int g = decltype(gc)::value;
 #pragma unroll
             for (int q = 0; q < kGatherJl; ++q) {
                 const int jl = g * kGatherJl + q;
                 if (jl < CW) {
                     const int j = jl * W + w;
                     const double xv = (j < D) ? p.x[(size_t)j * NP + chain] : 0.0;
-                    gp[(q * W + w) * kWave + lane] = xp[jl];
-                    gd[(q * W + w) * kWave + lane] = xp[jl] - xv;
+                    ulds[(q * W + w) * kWave + lane] = xp[jl];
+                    ulds[kGd + (q * W + w) * kWave + lane] = xp[jl] - xv;
                 }
             }
+        };
+        for (int g = 0; g < ngather; ++g) {
+            __syncthreads();
+            static_for<ngather>([&](auto gc) { if (g == decltype(gc)::value) write_panel(gc); });
             __syncthreads();
             if (w == 0) {
                 for (int q = 0; q < kGatherJl; ++q) {
                     for (int ww = 0; ww < W; ++ww) {
                         const int j = (g * kGatherJl + q) * W + ww;
                         if (j < D) {
-                            const double pj = gp[(q * W + ww) * kWave + lane];
-                            const double dj = gd[(q * W + ww) * kWave + lane];
+                            const double pj = ulds[(q * W + ww) * kWave + lane];
+                            const double dj = ulds[kGd + (q * W + ww) * kWave + lane];
                             if constexpr (EXACT) sqr += dj * dj;                     // :393-396
                             else sqr = SMCMC_FMA(dj, dj, sqr);
                             if constexpr (LIKE == SMCMC_LIKE_ISO_GAUSS) {

@@ -179,6 +179,32 @@ int smcmc_get_decomposition(smcmc_engine* h, double* out);/* fDecomposition, dim
 /* device pointers for zero-copy consumers (x: [dim_padded][nchains_padded], logl: [nchains_padded]) */
 int smcmc_state_device_ptr(smcmc_engine* h, double** x, double** logl);
 
+/* ---- Hamiltonian Monte Carlo (sMCMC::TSimpleHMC, reference TSimpleHMC.H:119-973) ------ */
+/* Every chain is an independent TSimpleHMC chain with the analytic gradient of the
+ * device likelihood.  The HIP path runs the fixed-step configuration of the reference:
+ * SetMeanEpsilon(negative value) keeps |epsilon| fixed (every update of fMeanEpsilon is
+ * guarded by fMeanEpsilon > 0, TSimpleHMC.H:304-343, 833-846) and SetLeapFrog(n) fixes the
+ * leapfrog count (:190, 302); smcmc_hmc_step returns SMCMC_ERR_UNSUPPORTED otherwise.
+ * Per-chain columns reuse smcmc_lane_f64 / smcmc_lane_i32: LOGL = -fAcceptedPotential,
+ * LOGL_PROPOSED = -fProposedPotential, ACCEPTANCE = fCurrentAcceptance, TRIALS = fStepCount,
+ * NACCEPT, LAST_ACCEPT. */
+typedef struct smcmc_hmc smcmc_hmc;
+int smcmc_hmc_create(int dim, int nchains, int likelihood, uint64_t seed, uint32_t chain_offset, int device,
+                     smcmc_hmc** out);                                   /* TSimpleHMC ctor :130 */
+int smcmc_hmc_destroy(smcmc_hmc* h);
+const char* smcmc_hmc_last_error(const smcmc_hmc* h);
+int smcmc_hmc_set_stream(smcmc_hmc* h, void* hip_stream);
+int smcmc_hmc_set_likelihood_params(smcmc_hmc* h, const double* params, int count);   /* GetLogLikelihood :157 */
+int smcmc_hmc_set_alpha(smcmc_hmc* h, double alpha);                     /* SetAlpha :175 */
+int smcmc_hmc_set_mean_epsilon(smcmc_hmc* h, double epsilon);            /* SetMeanEpsilon :181 (after Start, which resets it to 0.05) */
+int smcmc_hmc_get_mean_epsilon(smcmc_hmc* h, double* epsilon);           /* GetMeanEpsilon :184 */
+int smcmc_hmc_set_leapfrog(smcmc_hmc* h, int steps);                     /* SetLeapFrog :190 */
+int smcmc_hmc_start(smcmc_hmc* h, const double* x0, int broadcast);      /* Start :210-269 */
+int smcmc_hmc_step(smcmc_hmc* h, int nsteps);                            /* nsteps x Step(false) :279-401 */
+int smcmc_hmc_read_state(smcmc_hmc* h, double* q, double* momentum, double* logl);   /* fAccepted, fAcceptedMomentum */
+int smcmc_hmc_read_lane_f64(smcmc_hmc* h, int field, double* out);
+int smcmc_hmc_read_lane_i32(smcmc_hmc* h, int field, int32_t* out);
+
 /* ---- self test (no engine needed) --------------------------------------- */
 /* Runs every function of include/smcmc_detmath.h on the device for n inputs so
  * tests can compare device and host bit for bit.  kind: 0 log, 1 exp,

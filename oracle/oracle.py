@@ -25,7 +25,7 @@ _bp = C.POINTER(C.c_uint8)
 def build(force=False):
     """Compile the oracle with the committed Makefile (gcc, a second or two)."""
     srcs = [os.path.join(_HERE, f) for f in
-            ("smcmc_oracle.c", "ensemble_oracle.c", "oracle_core.h", "oracle_linalg.h")]
+            ("smcmc_oracle.c", "ensemble_oracle.c", "hmc_oracle.c", "oracle_core.h", "oracle_linalg.h")]
     srcs.append(os.path.join(_HERE, "..", "include", "smcmc_detmath.h"))
     stale = force or not os.path.exists(_LIB_PATH) or any(
         os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs if os.path.exists(s))
@@ -111,6 +111,23 @@ def _declare(L):
         f.argtypes = [C.c_void_p] + args
     L.oracle_ensemble_start.restype = C.c_int
     L.oracle_ensemble_start.argtypes = [C.c_void_p, _dp, C.c_int]
+
+    L.oracle_hmc_create.restype = C.c_void_p
+    L.oracle_hmc_create.argtypes = [C.c_int, C.c_int, _dp, C.c_int, C.c_uint64, C.c_uint32]
+    L.oracle_hmc_destroy.argtypes = [C.c_void_p]
+    L.oracle_hmc_set_alpha.argtypes = [C.c_void_p, C.c_double]
+    L.oracle_hmc_set_mean_epsilon.argtypes = [C.c_void_p, C.c_double]
+    L.oracle_hmc_set_leapfrog.argtypes = [C.c_void_p, C.c_int]
+    L.oracle_hmc_set_potential_from_gradient.argtypes = [C.c_void_p, C.c_int]
+    L.oracle_hmc_start.argtypes = [C.c_void_p, _dp]
+    L.oracle_hmc_step.restype = C.c_int
+    L.oracle_hmc_step.argtypes = [C.c_void_p]
+    L.oracle_hmc_run.argtypes = [C.c_void_p, C.c_int]
+    for name in ("accepted", "momentum", "central", "scalars"):
+        f = getattr(L, "oracle_hmc_get_" + name)
+        f.restype = None
+        f.argtypes = [C.c_void_p, _dp]
+    L.oracle_hmc_gradient.argtypes = [C.c_int, C.c_int, _dp, _dp, _dp]
 
 
 def _p(a):
@@ -342,3 +359,49 @@ def eigen(A):
 def loglike(kind, p, params=None):
     p = _f64(p); prm = like_params(kind, p.size, params)
     return lib().oracle_loglike(kind, p.size, _p(p), _p(prm) if prm.size else None)
+
+
+HMC_SCALARS = ["accepted_potential", "proposed_potential", "current_acceptance", "mean_epsilon",
+               "leapfrog_steps", "step_count", "potential_count", "gradient_count", "last_accept",
+               "central_potential"]
+
+
+class Hmc:
+    """One reference HMC chain: sMCMC::TSimpleHMC<L, analytic gradient>."""
+
+    def __init__(self, dim, kind=LIKE_ISO, params=None, seed=20240607, chain_id=0, potential_from_gradient=False):
+        self.dim = dim
+        prm = like_params(kind, dim, params)
+        self._h = lib().oracle_hmc_create(dim, kind, _p(prm) if prm.size else None, prm.size, seed, chain_id)
+        lib().oracle_hmc_set_potential_from_gradient(self._h, int(potential_from_gradient))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().oracle_hmc_destroy(self._h)
+            self._h = None
+
+    def set_alpha(self, a): lib().oracle_hmc_set_alpha(self._h, a)
+    def set_mean_epsilon(self, e): lib().oracle_hmc_set_mean_epsilon(self._h, e)
+    def set_leapfrog(self, n): lib().oracle_hmc_set_leapfrog(self._h, n)
+    def start(self, x0): lib().oracle_hmc_start(self._h, _p(_f64(x0)))
+    def step(self): return lib().oracle_hmc_step(self._h)
+    def run(self, n): lib().oracle_hmc_run(self._h, n)
+
+    def _vec(self, name, n):
+        out = np.zeros(n)
+        getattr(lib(), "oracle_hmc_get_" + name)(self._h, _p(out))
+        return out
+
+    accepted = property(lambda self: self._vec("accepted", self.dim))
+    momentum = property(lambda self: self._vec("momentum", self.dim))
+    central = property(lambda self: self._vec("central", self.dim))
+
+    @property
+    def scalars(self):
+        return dict(zip(HMC_SCALARS, self._vec("scalars", len(HMC_SCALARS))))
+
+
+def hmc_gradient(kind, p, params=None):
+    p = _f64(p); prm = like_params(kind, p.size, params); g = np.zeros_like(p)
+    lib().oracle_hmc_gradient(kind, p.size, _p(p), _p(prm) if prm.size else None, _p(g))
+    return g

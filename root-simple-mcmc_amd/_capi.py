@@ -72,6 +72,20 @@ SIGNATURES = {
     "smcmc_set_covariance": (C.c_int, [_H, _dp]),
     "smcmc_get_decomposition": (C.c_int, [_H, _dp]),
     "smcmc_state_device_ptr": (C.c_int, [_H, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "smcmc_hmc_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint32, C.c_int, C.POINTER(_H)]),
+    "smcmc_hmc_destroy": (C.c_int, [_H]),
+    "smcmc_hmc_last_error": (C.c_char_p, [_H]),
+    "smcmc_hmc_set_stream": (C.c_int, [_H, C.c_void_p]),
+    "smcmc_hmc_set_likelihood_params": (C.c_int, [_H, _dp, C.c_int]),
+    "smcmc_hmc_set_alpha": (C.c_int, [_H, C.c_double]),
+    "smcmc_hmc_set_mean_epsilon": (C.c_int, [_H, C.c_double]),
+    "smcmc_hmc_get_mean_epsilon": (C.c_int, [_H, _dp]),
+    "smcmc_hmc_set_leapfrog": (C.c_int, [_H, C.c_int]),
+    "smcmc_hmc_start": (C.c_int, [_H, _dp, C.c_int]),
+    "smcmc_hmc_step": (C.c_int, [_H, C.c_int]),
+    "smcmc_hmc_read_state": (C.c_int, [_H, _dp, _dp, _dp]),
+    "smcmc_hmc_read_lane_f64": (C.c_int, [_H, C.c_int, _dp]),
+    "smcmc_hmc_read_lane_i32": (C.c_int, [_H, C.c_int, _ip]),
     "smcmc_selftest_detmath": (C.c_int, [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp]),
     "smcmc_selftest_mfma": (C.c_int, [C.c_int, C.c_int, _dp, _dp, _dp]),
 }

@@ -42,12 +42,14 @@ def _headers():
 
 
 def _units():
-    units = [("smcmc_engine.hip", [], "engine"), ("smcmc_selftest.hip", [], "selftest")]
+    units = [("smcmc_engine.hip", [], "engine"), ("smcmc_selftest.hip", [], "selftest"),
+             ("smcmc_hmc_engine.hip", [], "hmc_engine")]
     for dp in dp_list():
         for like in LIKELIHOODS:
             units.append(("smcmc_inst.hip", [f"-DSMCMC_DP={dp}", f"-DSMCMC_LIKE={like}"], f"inst_dp{dp}_l{like}"))
     for w in (4, 8):
         units.append(("smcmc_panel_inst.hip", [f"-DSMCMC_PANEL_W={w}"], f"panel_w{w}"))
+        units.append(("smcmc_hmc_inst.hip", [f"-DSMCMC_PANEL_W={w}"], f"hmc_w{w}"))
     return units
 
 

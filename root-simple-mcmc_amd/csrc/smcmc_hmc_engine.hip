@@ -1,0 +1,229 @@
+// smcmc_hmc_engine.hip -- host engine behind the smcmc_hmc_* entry points of
+// include/smcmc.h: the many-chain form of sMCMC::TSimpleHMC (reference
+// TSimpleHMC.H:119-973) for a fixed step length and leapfrog count.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "smcmc.h"
+#include "smcmc_hmc_kernel.hip.h"
+
+using namespace smcmc;
+
+struct smcmc_hmc {
+    int dim = 0, nchains = 0, npad = 0, likelihood = 0, device = 0, W = 4;
+    uint64_t seed = 0;
+    uint32_t chain_offset = 0, step_count = 0;
+    bool started = false;
+    double alpha = 0.0;            // fAlpha, TSimpleHMC.H:133
+    double mean_epsilon = 0.05;    // fMeanEpsilon, set by Start (:229)
+    int leapfrog = 10;             // fLeapFrogSteps (:133); SetLeapFrog(n) stores -n (:190)
+    hipStream_t stream = nullptr;
+    std::vector<double> like_params;
+    double *d_q = nullptr, *d_pm = nullptr, *d_qn = nullptr, *d_pn = nullptr, *d_E = nullptr, *d_like = nullptr;
+    double* d_lane_f64 = nullptr;
+    int32_t* d_lane_i32 = nullptr;
+    std::string error;
+};
+
+namespace {
+
+int hfail(smcmc_hmc* h, int status, const std::string& msg) {
+    if (h) h->error = msg;
+    return status;
+}
+
+#define HMC_TRY(h, expr)                                                                     \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return hfail((h), SMCMC_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+HmcParams hmc_params(smcmc_hmc* h, int nsteps, int init_only) {
+    HmcParams p;
+    std::memset(&p, 0, sizeof(p));
+    p.nchains = h->nchains; p.npad = h->npad; p.dim = h->dim; p.nsteps = nsteps;
+    p.leapfrog = std::abs(h->leapfrog);                    // :300
+    p.init_only = init_only;
+    p.step0 = h->step_count; p.chain_offset = h->chain_offset; p.seed = h->seed;
+    p.alpha = h->alpha; p.abs_eps = std::fabs(h->mean_epsilon);
+    p.Eperm = h->d_E; p.like = h->d_like;
+    p.q = h->d_q; p.pm = h->d_pm; p.qn = h->d_qn; p.pn = h->d_pn;
+    p.lane_f64 = h->d_lane_f64; p.lane_i32 = h->d_lane_i32;
+    return p;
+}
+
+hipError_t hmc_dispatch(smcmc_hmc* h, const HmcParams& p) {
+    return (h->W == 4) ? launch_hmc<4, kPanelCW>(p, h->likelihood, h->stream)
+                       : launch_hmc<8, kPanelCW>(p, h->likelihood, h->stream);
+}
+
+}  // namespace
+
+extern "C" {
+
+int smcmc_hmc_create(int dim, int nchains, int likelihood, uint64_t seed, uint32_t chain_offset, int device,
+                     smcmc_hmc** out) {
+    if (!out) return SMCMC_ERR_INVALID;
+    *out = nullptr;
+    if (dim < 1 || nchains < 1) return SMCMC_ERR_INVALID;
+    if (likelihood < SMCMC_LIKE_ISO_GAUSS || likelihood > SMCMC_LIKE_ROSENBROCK) return SMCMC_ERR_INVALID;
+    if (likelihood == SMCMC_LIKE_ROSENBROCK && dim < 2) return SMCMC_ERR_INVALID;
+    if (dim > 8 * kPanelCW) return SMCMC_ERR_UNSUPPORTED;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return SMCMC_ERR_NO_DEVICE;
+    if (device < 0 || device >= ndev) return SMCMC_ERR_NO_DEVICE;
+    smcmc_hmc* h = new (std::nothrow) smcmc_hmc();
+    if (!h) return SMCMC_ERR_RUNTIME;
+    h->dim = dim; h->nchains = nchains; h->likelihood = likelihood; h->seed = seed;
+    h->chain_offset = chain_offset; h->device = device;
+    h->W = (dim <= 4 * kPanelCW) ? 4 : 8;
+    h->npad = (nchains + kWave - 1) / kWave * kWave;
+    *out = h;
+    HMC_TRY(h, hipSetDevice(device));
+    const size_t vec = sizeof(double) * (size_t)h->npad * dim;
+    HMC_TRY(h, hipMalloc(&h->d_q, vec));
+    HMC_TRY(h, hipMalloc(&h->d_pm, vec));
+    HMC_TRY(h, hipMalloc(&h->d_qn, vec));
+    HMC_TRY(h, hipMalloc(&h->d_pn, vec));
+    HMC_TRY(h, hipMalloc(&h->d_E, sizeof(double) * (size_t)h->W * dim * kPanelCW));
+    HMC_TRY(h, hipMalloc(&h->d_like, sizeof(double) * 8));
+    HMC_TRY(h, hipMalloc(&h->d_lane_f64, sizeof(double) * (size_t)h->npad * SMCMC_LANE_F64_COUNT_));
+    HMC_TRY(h, hipMalloc(&h->d_lane_i32, sizeof(int32_t) * (size_t)h->npad * SMCMC_LANE_I32_COUNT_));
+    HMC_TRY(h, hipMemset(h->d_q, 0, vec));
+    HMC_TRY(h, hipMemset(h->d_pm, 0, vec));
+    HMC_TRY(h, hipMemset(h->d_qn, 0, vec));
+    HMC_TRY(h, hipMemset(h->d_pn, 0, vec));
+    HMC_TRY(h, hipMemset(h->d_E, 0, sizeof(double) * (size_t)h->W * dim * kPanelCW));
+    HMC_TRY(h, hipMemset(h->d_like, 0, sizeof(double) * 8));
+    HMC_TRY(h, hipMemset(h->d_lane_f64, 0, sizeof(double) * (size_t)h->npad * SMCMC_LANE_F64_COUNT_));
+    HMC_TRY(h, hipMemset(h->d_lane_i32, 0, sizeof(int32_t) * (size_t)h->npad * SMCMC_LANE_I32_COUNT_));
+    return SMCMC_OK;
+}
+
+int smcmc_hmc_destroy(smcmc_hmc* h) {
+    if (!h) return SMCMC_OK;
+    if (h->d_q) {
+        (void)hipSetDevice(h->device);
+        (void)hipStreamSynchronize(h->stream);
+    }
+    (void)hipFree(h->d_q); (void)hipFree(h->d_pm); (void)hipFree(h->d_qn); (void)hipFree(h->d_pn);
+    (void)hipFree(h->d_E); (void)hipFree(h->d_like); (void)hipFree(h->d_lane_f64); (void)hipFree(h->d_lane_i32);
+    delete h;
+    return SMCMC_OK;
+}
+
+const char* smcmc_hmc_last_error(const smcmc_hmc* h) { return h ? h->error.c_str() : "null engine"; }
+
+int smcmc_hmc_set_stream(smcmc_hmc* h, void* hip_stream) {
+    if (!h) return SMCMC_ERR_INVALID;
+    h->stream = (hipStream_t)hip_stream;
+    return SMCMC_OK;
+}
+
+int smcmc_hmc_set_likelihood_params(smcmc_hmc* h, const double* params, int count) {
+    if (!h || count < 0 || (count > 0 && !params)) return SMCMC_ERR_INVALID;
+    h->like_params.assign(params, params + count);
+    return SMCMC_OK;
+}
+
+int smcmc_hmc_set_alpha(smcmc_hmc* h, double a) { if (!h) return SMCMC_ERR_INVALID; h->alpha = a; return SMCMC_OK; }
+int smcmc_hmc_set_mean_epsilon(smcmc_hmc* h, double e) { if (!h) return SMCMC_ERR_INVALID; h->mean_epsilon = e; return SMCMC_OK; }
+int smcmc_hmc_set_leapfrog(smcmc_hmc* h, int n) { if (!h) return SMCMC_ERR_INVALID; h->leapfrog = -n; return SMCMC_OK; }
+int smcmc_hmc_get_mean_epsilon(smcmc_hmc* h, double* e) { if (!h || !e) return SMCMC_ERR_INVALID; *e = h->mean_epsilon; return SMCMC_OK; }
+
+int smcmc_hmc_start(smcmc_hmc* h, const double* x0, int broadcast) {
+    if (!h || !x0) return SMCMC_ERR_INVALID;
+    HMC_TRY(h, hipSetDevice(h->device));
+    const int D = h->dim, N = h->nchains, W = h->W;
+    const size_t NP = (size_t)h->npad;
+    if (h->likelihood == SMCMC_LIKE_QUADFORM) {
+        if ((int)h->like_params.size() != D * D)
+            return hfail(h, SMCMC_ERR_INVALID, "QUADFORM needs dim*dim likelihood parameters (the Error matrix)");
+        // Eperm[w][j][il] = Error(il*W + w, j): the rows a wavefront owns, contiguous per source column j
+        std::vector<double> perm((size_t)W * D * kPanelCW, 0.0);
+        for (int w = 0; w < W; ++w)
+            for (int j = 0; j < D; ++j)
+                for (int il = 0; il < kPanelCW; ++il) {
+                    const int i = il * W + w;
+                    if (i < D) perm[((size_t)w * D + j) * kPanelCW + il] = h->like_params[(size_t)i * D + j];
+                }
+        HMC_TRY(h, hipMemcpyAsync(h->d_E, perm.data(), perm.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        HMC_TRY(h, hipStreamSynchronize(h->stream));
+    }
+    double b = 100.0;
+    if (h->likelihood == SMCMC_LIKE_ROSENBROCK && !h->like_params.empty()) b = h->like_params[0];
+    HMC_TRY(h, hipMemcpyAsync(h->d_like, &b, sizeof(double), hipMemcpyHostToDevice, h->stream));
+    std::vector<double> x(NP * D, 0.0);
+    for (int d = 0; d < D; ++d)
+        for (int c = 0; c < N; ++c) x[(size_t)d * NP + c] = broadcast ? x0[d] : x0[(size_t)d * N + c];
+    HMC_TRY(h, hipMemcpyAsync(h->d_q, x.data(), x.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HMC_TRY(h, hipMemsetAsync(h->d_pm, 0, sizeof(double) * NP * D, h->stream));
+    HMC_TRY(h, hipMemsetAsync(h->d_lane_f64, 0, sizeof(double) * NP * SMCMC_LANE_F64_COUNT_, h->stream));
+    HMC_TRY(h, hipMemsetAsync(h->d_lane_i32, 0, sizeof(int32_t) * NP * SMCMC_LANE_I32_COUNT_, h->stream));
+    h->step_count = 0;                                   // :211
+    h->mean_epsilon = 0.05;                              // :229
+    HmcParams p = hmc_params(h, 0, 1);
+    hipError_t e = hmc_dispatch(h, p);
+    if (e != hipSuccess) return hfail(h, SMCMC_ERR_HIP, std::string("hmc start launch: ") + hipGetErrorString(e));
+    // fCurrentAcceptance = fTargetAcceptance = 0.65 (:234-235)
+    std::vector<double> acc(NP, 0.0);
+    for (int c = 0; c < N; ++c) acc[c] = 0.65;
+    HMC_TRY(h, hipMemcpyAsync(h->d_lane_f64 + (size_t)SMCMC_LANE_ACCEPTANCE * NP, acc.data(), NP * sizeof(double),
+                              hipMemcpyHostToDevice, h->stream));
+    HMC_TRY(h, hipStreamSynchronize(h->stream));
+    h->started = true;
+    return SMCMC_OK;
+}
+
+int smcmc_hmc_step(smcmc_hmc* h, int nsteps) {
+    if (!h) return SMCMC_ERR_INVALID;
+    if (!h->started) return hfail(h, SMCMC_ERR_INVALID, "Must initialize starting point");   // :280-284
+    if (nsteps <= 0) return SMCMC_OK;
+    if (h->mean_epsilon > 0.0 || h->leapfrog > 0)
+        return hfail(h, SMCMC_ERR_UNSUPPORTED,
+                     "the HIP path runs a fixed step: SetMeanEpsilon(negative) and SetLeapFrog(n) after Start "
+                     "(covariance-driven tuning of epsilon / leapfrog count is not on the device yet)");
+    HmcParams p = hmc_params(h, nsteps, 0);
+    hipError_t e = hmc_dispatch(h, p);
+    if (e != hipSuccess) return hfail(h, SMCMC_ERR_HIP, std::string("hmc step launch: ") + hipGetErrorString(e));
+    h->step_count += (uint32_t)nsteps;
+    return SMCMC_OK;
+}
+
+int smcmc_hmc_read_state(smcmc_hmc* h, double* q, double* momentum, double* logl) {
+    if (!h) return SMCMC_ERR_INVALID;
+    const int D = h->dim, N = h->nchains;
+    const size_t NP = (size_t)h->npad;
+    HMC_TRY(h, hipStreamSynchronize(h->stream));
+    if (q) HMC_TRY(h, hipMemcpy2D(q, (size_t)N * sizeof(double), h->d_q, NP * sizeof(double), (size_t)N * sizeof(double),
+                                  (size_t)D, hipMemcpyDeviceToHost));
+    if (momentum) HMC_TRY(h, hipMemcpy2D(momentum, (size_t)N * sizeof(double), h->d_pm, NP * sizeof(double),
+                                         (size_t)N * sizeof(double), (size_t)D, hipMemcpyDeviceToHost));
+    if (logl) HMC_TRY(h, hipMemcpy(logl, h->d_lane_f64 + (size_t)SMCMC_LANE_LOGL * NP, (size_t)N * sizeof(double),
+                                   hipMemcpyDeviceToHost));
+    return SMCMC_OK;
+}
+
+int smcmc_hmc_read_lane_f64(smcmc_hmc* h, int field, double* out) {
+    if (!h || !out || field < 0 || field >= SMCMC_LANE_F64_COUNT_) return SMCMC_ERR_INVALID;
+    HMC_TRY(h, hipStreamSynchronize(h->stream));
+    HMC_TRY(h, hipMemcpy(out, h->d_lane_f64 + (size_t)field * h->npad, (size_t)h->nchains * sizeof(double),
+                         hipMemcpyDeviceToHost));
+    return SMCMC_OK;
+}
+
+int smcmc_hmc_read_lane_i32(smcmc_hmc* h, int field, int32_t* out) {
+    if (!h || !out || field < 0 || field >= SMCMC_LANE_I32_COUNT_) return SMCMC_ERR_INVALID;
+    HMC_TRY(h, hipStreamSynchronize(h->stream));
+    HMC_TRY(h, hipMemcpy(out, h->d_lane_i32 + (size_t)field * h->npad, (size_t)h->nchains * sizeof(int32_t),
+                         hipMemcpyDeviceToHost));
+    return SMCMC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,405 @@
+// smcmc_hmc_kernel.hip.h -- many-chain Hamiltonian Monte Carlo step, the device side of
+// sMCMC::TSimpleHMC::Step() (reference TSimpleHMC.H:279-401) with a fixed step
+// length |fMeanEpsilon| and a fixed leapfrog count (SetLeapFrog, TSimpleHMC.H:190):
+//   ProposeMomentum (:554-570), KineticEnergy (:535-542), epsilon draw (:297),
+//   LeapFrog (:582-651: L steps = L+1 gradient calls), Potential (:411-414), the
+//   Hamiltonian test with momentum flip on reject (:346-387) and the acceptance
+//   average (:367, 386).
+// Every chain is an independent reference chain (HMC shares no adaptive state once
+// epsilon and L are fixed).  Layout as in smcmc_panel_kernel.hip.h: a workgroup of W
+// wavefronts per 64-chain group, lane = chain, wavefront w owns the components
+// i = il * W + w.  Positions and momenta live in HBM as [dim][chain]; only the
+// gradient accumulators of the owned components sit in registers.  The gradient of
+// the quadratic-form likelihood (TDummyLogLikelihood.H:34-42), g_i -= Error(i,j) q_j,
+// is the D x D contraction of the path: the row panel of q goes through LDS, the
+// wavefront's slice of Error^T through its own LDS staging area.
+// Sums that the reference runs in index order over all components (kinetic energy,
+// log-likelihood) are walked by wavefront 0 over LDS gather panels.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "smcmc.h"
+#include "smcmc_detmath.h"
+#include "smcmc_kernels.hip.h"
+#include "smcmc_panel_kernel.hip.h"
+
+namespace smcmc {
+
+struct HmcParams {
+    int nchains, npad, dim, nsteps, leapfrog, init_only;
+    uint32_t step0, chain_offset;
+    uint64_t seed;
+    double alpha, abs_eps;
+    const double* Eperm;   // QUADFORM: [W][dim][CW], Eperm[w][j][il] = Error(il*W + w, j)
+    const double* like;    // ROSENBROCK: {b}
+    double* q;             // accepted position   [dim][npad]
+    double* pm;            // accepted momentum   [dim][npad]
+    double* qn;            // proposed position   [dim][npad]
+    double* pn;            // proposed momentum   [dim][npad]
+    double* lane_f64;      // LOGL = -accepted potential, LOGL_PROPOSED = -proposed potential, ACCEPTANCE
+    int32_t* lane_i32;     // NACCEPT, LAST_ACCEPT, TRIALS = step count
+};
+
+template <int W, int CW, int LIKE>
+__global__ void __launch_bounds__(W * kWave) hmc_step_kernel(const HmcParams p) {
+    __shared__ double rbuf[kPanelRows * kWave];                                   // q rows of the current panel
+    __shared__ __attribute__((aligned(16))) double ulds[W * kPanelRows * CW];     // Error^T panels / gather panels
+    __shared__ double verdict_f[kWave];
+    __shared__ int verdict_i[kWave];
+    constexpr int kGd = kGatherJl * W * kWave;
+    constexpr int ngather = (CW + kGatherJl - 1) / kGatherJl;
+
+    const int lane = threadIdx.x & (kWave - 1);
+    const int w = threadIdx.x / kWave;
+    const int chain = blockIdx.x * kWave + lane;
+    const bool active = chain < p.nchains;
+    const int D = p.dim;
+    const size_t NP = (size_t)p.npad;
+    const uint32_t gid = p.chain_offset + (uint32_t)chain;
+    const int npanels = (D + kPanelRows - 1) / kPanelRows;
+    const uint32_t ew = smcmc_accept_word((uint32_t)D);
+    const double rb = (LIKE == SMCMC_LIKE_ROSENBROCK) ? p.like[0] : 0.0;
+
+    double* lf = p.lane_f64 + chain;
+    int32_t* li = p.lane_i32 + chain;
+    double pot_acc = -lf[SMCMC_LANE_LOGL * NP];
+    double pot_prop = -lf[SMCMC_LANE_LOGL_PROPOSED * NP];
+    double acceptance = lf[SMCMC_LANE_ACCEPTANCE * NP];
+    int naccept = li[SMCMC_LANE_NACCEPT * NP];
+    int last_accept = li[SMCMC_LANE_LAST_ACCEPT * NP];
+    int trials = li[SMCMC_LANE_TRIALS * NP];
+
+    double gr[CW];   // potential gradient of the owned components
+
+    // walks `count` values per chain, dimension order, through wavefront 0:
+    // each owner publishes f(il) for its components, wavefront 0 folds them with `fold`
+    auto gather = [&](auto&& value_of, auto&& fold) {
+        for (int g = 0; g < ngather; ++g) {
+            __syncthreads();
+            static_for<ngather>([&](auto gc) {
+                if (g == decltype(gc)::value) {
+#pragma unroll
+                    for (int qq = 0; qq < kGatherJl; ++qq) {
+                        constexpr int gg = decltype(gc)::value;
+                        const int il = gg * kGatherJl + qq;
+                        if (il < CW) {
+                            double a, b;
+                            value_of(il, a, b);
+                            ulds[(qq * W + w) * kWave + lane] = a;
+                            ulds[kGd + (qq * W + w) * kWave + lane] = b;
+                        }
+                    }
+                }
+            });
+            __syncthreads();
+            if (w == 0) {
+                for (int qq = 0; qq < kGatherJl; ++qq)
+                    for (int ww = 0; ww < W; ++ww) {
+                        const int i = (g * kGatherJl + qq) * W + ww;
+                        if (i < D) fold(i, ulds[(qq * W + ww) * kWave + lane], ulds[kGd + (qq * W + ww) * kWave + lane]);
+                    }
+            }
+        }
+        __syncthreads();
+    };
+
+    // potential gradient at qn for the owned components -> gr[]  (PotentialGradient type 0
+    // with the user gradient, TSimpleHMC.H:467-492: the negated gradient of log L)
+    auto gradient = [&]() {
+        __syncthreads();   // every owner has written its part of qn
+        if constexpr (LIKE == SMCMC_LIKE_ISO_GAUSS) {
+#pragma unroll
+            for (int il = 0; il < CW; ++il) {
+                const int i = il * W + w;
+                const double g = (i < D) ? -p.qn[(size_t)i * NP + chain] : 0.0;   // g[i] = -p[i]
+                gr[il] = -g;
+            }
+        } else if constexpr (LIKE == SMCMC_LIKE_ROSENBROCK) {
+            // THardLogLikelihood.H:70-91, then g = -g twice (log L -> potential)
+#pragma unroll
+            for (int il = 0; il < CW; ++il) {
+                const int i = il * W + w;
+                double g = 0.0;
+                if (i < D) {
+                    const double pi = p.qn[(size_t)i * NP + chain];
+                    if (i == 0) {
+                        const double p1 = p.qn[NP + chain];
+                        g = -2.0 * (1.0 - pi) - 4.0 * rb * pi * (p1 - pi * pi);
+                    } else if (i < D - 1) {
+                        const double pm1 = p.qn[(size_t)(i - 1) * NP + chain];
+                        const double pp1 = p.qn[(size_t)(i + 1) * NP + chain];
+                        g = 2.0 * rb * (pi - pm1 * pm1);
+                        g += -2.0 * (1.0 - pi);
+                        g += -4.0 * rb * pi * (pp1 - pi * pi);
+                    } else {
+                        const double pm1 = p.qn[(size_t)(i - 1) * NP + chain];
+                        g = +2.0 * rb * (pi - pm1 * pm1);
+                    }
+                    g = -g;        // THardLogLikelihood.H:88
+                }
+                gr[il] = -g;       // TSimpleHMC.H:486
+            }
+        } else {
+            // TDummyLogLikelihood.H:34-42: g[i] = 0; g[i] -= Error(i,j)*p[j], j ascending
+#pragma unroll
+            for (int il = 0; il < CW; ++il) gr[il] = 0.0;
+            for (int pnl = 0; pnl < npanels; ++pnl) {
+                const int j0 = pnl * kPanelRows;
+                const int j1 = (j0 + kPanelRows < D) ? j0 + kPanelRows : D;
+                __syncthreads();
+                for (int r = w; r < j1 - j0; r += W) rbuf[r * kWave + lane] = p.qn[(size_t)(j0 + r) * NP + chain];
+                {
+                    const f64x2* src = (const f64x2*)(p.Eperm + ((size_t)w * D + j0) * CW);
+                    f64x2* dst = (f64x2*)(ulds + w * (kPanelRows * CW));
+                    const int npieces = (j1 - j0) * (CW / 2);
+                    for (int k = lane; k < npieces; k += kWave) dst[k] = src[k];
+                }
+                __syncthreads();
+                lds_cptr_f64 up = (lds_cptr_f64)(ulds + w * (kPanelRows * CW));
+                asm volatile("" : "+v"(up));
+                for (int j = j0; j < j1; ++j) {
+                    const double qj = rbuf[(j - j0) * kWave + lane];
+                    lds_cptr_f64 erow = up + (j - j0) * CW;
+#pragma unroll
+                    for (int c = 0; c < CW; c += 16) {
+                        f64x2 e2[8];
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) e2[k] = *(volatile lds_cptr_f64x2)(erow + c + 2 * k);
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) {
+                            gr[c + k] -= e2[k / 2][k & 1] * qj;
+                            asm volatile("" : "+v"(gr[c + k]));
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int il = 0; il < CW; ++il) gr[il] = -gr[il];   // TSimpleHMC.H:486
+            __syncthreads();
+        }
+    };
+
+    // log L at qn (valid in wavefront 0) and, on the way, the kinetic energy of pn
+    auto log_likelihood_at_qn = [&](bool gradient_is_current, double& ke) {
+        double lsum = 0.0, prev_q = 0.0;
+        gather([&](int il, double& a, double& b) {
+                   const int i = il * W + w;
+                   a = (i < D) ? p.pn[(size_t)i * NP + chain] : 0.0;
+                   b = (i < D) ? p.qn[(size_t)i * NP + chain] : 0.0;
+               },
+               [&](int i, double a, double b) {
+                   ke += a * a / 2.0;
+                   if constexpr (LIKE == SMCMC_LIKE_ISO_GAUSS) {
+                       lsum += -0.5 * b * b;                                   // README.md:57-66
+                   } else if constexpr (LIKE == SMCMC_LIKE_ROSENBROCK) {
+                       if (i > 0) {                                            // THardLogLikelihood.H:60-64, term i-1
+                           const double aa = (1.0 - prev_q);
+                           const double bb = b - prev_q * prev_q;
+                           lsum -= aa * aa + rb * bb * bb;
+                       }
+                       prev_q = b;
+                   }
+               });
+        if constexpr (LIKE == SMCMC_LIKE_QUADFORM) {
+            // log L = -1/2 q^T Error q.  The gradient at the final position is still in gr[]
+            // (gr = Error q): the potential is folded from it in dimension order instead of
+            // re-running the D^2-term sum of TDummyLogLikelihood.H:24-28 serially.
+            if (!gradient_is_current) gradient();
+            double usum = 0.0;
+            gather([&](int il, double& a, double& b) {
+                       const int i = il * W + w;
+                       a = (i < D) ? p.qn[(size_t)i * NP + chain] : 0.0;
+                       b = gr[il];
+                   },
+                   [&](int, double a, double b) { usum += 0.5 * a * b; });
+            lsum = -usum;
+        }
+        return lsum;
+    };
+
+    if (p.init_only) {
+        // Start (:210-269): SetPosition's Potential(start) for every chain
+#pragma unroll
+        for (int il = 0; il < CW; ++il) {
+            const int i = il * W + w;
+            if (i < D) {
+                p.qn[(size_t)i * NP + chain] = p.q[(size_t)i * NP + chain];
+                p.pn[(size_t)i * NP + chain] = 0.0;
+            }
+        }
+        __syncthreads();
+        double ke = 0.0;
+        const double l0 = log_likelihood_at_qn(false, ke);
+        if (w == 0 && active) {
+            lf[SMCMC_LANE_LOGL * NP] = l0;
+            lf[SMCMC_LANE_LOGL_PROPOSED * NP] = l0;
+        }
+        return;
+    }
+
+    for (int s = 0; s < p.nsteps; ++s) {
+        const uint64_t step = (uint64_t)(p.step0 + (uint32_t)s + 1u);   // ++fStepCount, :286
+        ++trials;
+
+        // ---- ProposeMomentum (:554-570) for the owned components ----
+        const double mix = __builtin_sqrt(1.0 - p.alpha * p.alpha);
+#pragma unroll
+        for (int il = 0; il < CW; ++il) {
+            const int i = il * W + w;
+            if (i < D) {
+                const double m = p.pm[(size_t)i * NP + chain];
+                double v;
+                if (p.alpha >= 1.0) {
+                    v = m / p.alpha;
+                } else {
+                    const uint32_t pr = (uint32_t)i >> 1;
+                    smcmc_u32x4 blk = smcmc_draw_block(p.seed, gid, step, pr >> 1, SMCMC_STREAM_HMC);
+                    double n0, n1;
+                    const uint32_t w0 = (pr & 1u) ? blk.v[2] : blk.v[0], w1 = (pr & 1u) ? blk.v[3] : blk.v[1];
+                    smcmc_normal_pair(w0, w1, &n0, &n1);
+                    const double r = (i & 1) ? n1 : n0;
+                    v = p.alpha * m + mix * r;
+                }
+                p.pn[(size_t)i * NP + chain] = v;
+                p.qn[(size_t)i * NP + chain] = p.q[(size_t)i * NP + chain];   // LeapFrog: qNew = position (:586)
+            }
+        }
+        // ---- initial kinetic energy (:292), dimension order ----
+        double ke0 = 0.0;
+        gather([&](int il, double& a, double& b) {
+                   const int i = il * W + w;
+                   a = (i < D) ? p.pn[(size_t)i * NP + chain] : 0.0;
+                   b = 0.0;
+               },
+               [&](int, double a, double) { ke0 += a * a / 2.0; });
+
+        // ---- epsilon (:297-298) ----
+        const smcmc_u32x4 eblk = smcmc_draw_block(p.seed, gid, step, ew >> 2, SMCMC_STREAM_HMC);
+        const double lo = 0.9 * p.abs_eps, hi = 1.1 * p.abs_eps;
+        const double eps = lo + (hi - lo) * smcmc_u01(smcmc_select_word(eblk, ew & 3u));
+        const smcmc_u32x4 ablk = smcmc_draw_block(p.seed, gid, step, (ew + 1u) >> 2, SMCMC_STREAM_HMC);
+        const double uacc = smcmc_u01(smcmc_select_word(ablk, (ew + 1u) & 3u));
+
+        // ---- LeapFrog (:582-651) ----
+        const int L = p.leapfrog;
+        if (L < 1) {
+            // the one-step shortcut (:598-611): qNew += eps*(momentum + pNew)/2 with pNew == momentum
+#pragma unroll
+            for (int il = 0; il < CW; ++il) {
+                const int i = il * W + w;
+                if (i < D) {
+                    const double m = p.pn[(size_t)i * NP + chain];
+                    const double qv = p.qn[(size_t)i * NP + chain];
+                    p.qn[(size_t)i * NP + chain] = qv + eps * (m + m) / 2.0;
+                }
+            }
+        } else {
+            gradient();                                                        // :615
+#pragma unroll
+            for (int il = 0; il < CW; ++il) {                                  // :618-620
+                const int i = il * W + w;
+                if (i < D) {
+                    const double m = p.pn[(size_t)i * NP + chain];
+                    p.pn[(size_t)i * NP + chain] = m - eps * gr[il] / 2.0;
+                }
+            }
+            for (int ls = 0; ls < L - 1; ++ls) {                               // :623-639
+#pragma unroll
+                for (int il = 0; il < CW; ++il) {
+                    const int i = il * W + w;
+                    if (i < D) {
+                        const double m = p.pn[(size_t)i * NP + chain];
+                        const double qv = p.qn[(size_t)i * NP + chain];
+                        p.qn[(size_t)i * NP + chain] = qv + eps * m;
+                    }
+                }
+                gradient();
+#pragma unroll
+                for (int il = 0; il < CW; ++il) {
+                    const int i = il * W + w;
+                    if (i < D) {
+                        const double m = p.pn[(size_t)i * NP + chain];
+                        p.pn[(size_t)i * NP + chain] = m - eps * gr[il];
+                    }
+                }
+                // the reversal test (:633-638) only feeds the leapfrog auto-tuning, which
+                // SetLeapFrog switches off
+            }
+#pragma unroll
+            for (int il = 0; il < CW; ++il) {                                  // :641-643
+                const int i = il * W + w;
+                if (i < D) {
+                    const double m = p.pn[(size_t)i * NP + chain];
+                    const double qv = p.qn[(size_t)i * NP + chain];
+                    p.qn[(size_t)i * NP + chain] = qv + eps * m;
+                }
+            }
+            gradient();                                                        // :645
+#pragma unroll
+            for (int il = 0; il < CW; ++il) {                                  // :646-648
+                const int i = il * W + w;
+                if (i < D) {
+                    const double m = p.pn[(size_t)i * NP + chain];
+                    p.pn[(size_t)i * NP + chain] = m - eps * gr[il] / 2.0;
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- proposed kinetic energy and potential (:326-327), dimension order ----
+        double ke1 = 0.0;
+        const double lsum = log_likelihood_at_qn(L >= 1, ke1);
+
+        // ---- Hamiltonian test (:333-387), wavefront 0 decides ----
+        if (w == 0) {
+            pot_prop = -lsum;
+            const double h_prop = pot_prop + ke1;
+            const double h_acc = pot_acc + ke0;
+            const double delta = h_prop - h_acc;
+            const double trial = -smcmc_log_pos(uacc);
+            const bool reject = (delta > trial) || !__builtin_isfinite(delta) || !active;
+            verdict_i[lane] = reject ? 0 : 1;
+            verdict_f[lane] = pot_prop;
+        }
+        __syncthreads();
+        const bool take = verdict_i[lane] != 0;
+        pot_prop = verdict_f[lane];
+        if (take) {
+            pot_acc = pot_prop;
+            acceptance = (acceptance * 4999.0 + 1.0) / 5000.0;                  // :386
+            ++naccept;
+        } else {
+            acceptance = (acceptance * 4999.0) / 5000.0;                        // :367
+        }
+        last_accept = take ? 1 : 0;
+#pragma unroll
+        for (int il = 0; il < CW; ++il) {
+            const int i = il * W + w;
+            if (i < D && active) {
+                if (take) {                                                     // :380-383
+                    p.q[(size_t)i * NP + chain] = p.qn[(size_t)i * NP + chain];
+                    p.pm[(size_t)i * NP + chain] = p.pn[(size_t)i * NP + chain];
+                } else {                                                        // :364-366
+                    p.pm[(size_t)i * NP + chain] = -p.pm[(size_t)i * NP + chain];
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    if (active && w == 0) {
+        lf[SMCMC_LANE_LOGL * NP] = -pot_acc;
+        lf[SMCMC_LANE_LOGL_PROPOSED * NP] = -pot_prop;
+        lf[SMCMC_LANE_ACCEPTANCE * NP] = acceptance;
+        li[SMCMC_LANE_NACCEPT * NP] = naccept;
+        li[SMCMC_LANE_LAST_ACCEPT * NP] = last_accept;
+        li[SMCMC_LANE_TRIALS * NP] = trials;
+    }
+}
+
+template <int W, int CW>
+hipError_t launch_hmc(const HmcParams& p, int like, hipStream_t stream);
+
+}  // namespace smcmc

@@ -250,3 +250,79 @@ def selftest_mfma(a, b, device=0):
     if st != _capi.OK:
         raise SmcmcError(st, lib.smcmc_status_string(st).decode())
     return c
+
+
+class HmcEngine:
+    """N independent sMCMC::TSimpleHMC chains (reference TSimpleHMC.H:119-973) with the
+    analytic gradient of a device likelihood, fixed |epsilon| and leapfrog count."""
+
+    def __init__(self, dim, nchains=1, likelihood=LIKE_ISO_GAUSS, likelihood_params=None, seed=20240607,
+                 chain_offset=0, device=0, stream=None):
+        self._lib = _capi.load()
+        self.dim, self.nchains = int(dim), int(nchains)
+        h = C.c_void_p()
+        st = self._lib.smcmc_hmc_create(self.dim, self.nchains, likelihood, seed, chain_offset, device, C.byref(h))
+        self._h = h
+        if st != _capi.OK:
+            msg = self._lib.smcmc_hmc_last_error(h).decode() if h else self._lib.smcmc_status_string(st).decode()
+            if h:
+                self._lib.smcmc_hmc_destroy(h)
+            self._h = None
+            raise SmcmcError(st, msg)
+        if likelihood_params is not None:
+            prm = _f64(likelihood_params).ravel()
+            self._check(self._lib.smcmc_hmc_set_likelihood_params(self._h, _ptr(prm), prm.size))
+        if stream is not None:
+            self._check(self._lib.smcmc_hmc_set_stream(self._h, C.c_void_p(int(stream))))
+
+    def _check(self, st):
+        if st != _capi.OK:
+            raise SmcmcError(st, self._lib.smcmc_hmc_last_error(self._h).decode()
+                             or self._lib.smcmc_status_string(st).decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.smcmc_hmc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def SetAlpha(self, a): self._check(self._lib.smcmc_hmc_set_alpha(self._h, float(a)))
+    def SetMeanEpsilon(self, e): self._check(self._lib.smcmc_hmc_set_mean_epsilon(self._h, float(e)))
+    def SetLeapFrog(self, n): self._check(self._lib.smcmc_hmc_set_leapfrog(self._h, int(n)))
+
+    def GetMeanEpsilon(self):
+        out = C.c_double(0)
+        self._check(self._lib.smcmc_hmc_get_mean_epsilon(self._h, C.byref(out)))
+        return out.value
+
+    def Start(self, start):
+        start = _f64(start)
+        broadcast = int(start.ndim == 1)
+        if not broadcast and start.shape != (self.dim, self.nchains):
+            raise ValueError("start must be [dim] or [dim][nchains]")
+        self._check(self._lib.smcmc_hmc_start(self._h, _ptr(start), broadcast))
+
+    def Step(self, nsteps=1):
+        self._check(self._lib.smcmc_hmc_step(self._h, int(nsteps)))
+
+    def state(self):
+        q = np.zeros((self.dim, self.nchains))
+        m = np.zeros((self.dim, self.nchains))
+        logl = np.zeros(self.nchains)
+        self._check(self._lib.smcmc_hmc_read_state(self._h, _ptr(q), _ptr(m), _ptr(logl)))
+        return q, m, logl
+
+    def lane(self, name):
+        if name in _capi.LANE_F64:
+            out = np.zeros(self.nchains)
+            self._check(self._lib.smcmc_hmc_read_lane_f64(self._h, _capi.LANE_F64[name], _ptr(out)))
+            return out
+        out = np.zeros(self.nchains, np.int32)
+        self._check(self._lib.smcmc_hmc_read_lane_i32(self._h, _capi.LANE_I32[name],
+                                                      out.ctypes.data_as(C.POINTER(C.c_int32))))
+        return out

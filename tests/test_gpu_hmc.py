@@ -1,0 +1,92 @@
+"""HMC on the GPU (smcmc_hmc_*, BASELINE config 5 shape) against the CPU restatement of
+sMCMC::TSimpleHMC (oracle/hmc_oracle.c): every chain is an independent reference chain."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _spd(dim, seed):
+    rng = np.random.default_rng(seed)
+    a = rng.standard_normal((dim, dim)) / np.sqrt(dim)
+    return a @ a.T + np.eye(dim)
+
+
+def _check(gpu, oracle, dim, nchains, kind, params, x0, eps, leap, steps, alpha=0.0, chains=(0, 1, 63, 64)):
+    e = gpu.HmcEngine(dim, nchains, likelihood=kind, likelihood_params=params, seed=99)
+    e.SetAlpha(alpha)
+    e.Start(x0)
+    e.SetMeanEpsilon(-eps)         # fixed step length: fMeanEpsilon < 0 (TSimpleHMC.H:297, 304-343)
+    e.SetLeapFrog(leap)
+    e.Step(1)
+    e.Step(steps - 1)
+    q, m, logl = e.state()
+    for ch in chains:
+        if ch >= nchains:
+            continue
+        h = oracle.Hmc(dim, kind=kind, params=params, seed=99, chain_id=ch, potential_from_gradient=True)
+        h.set_alpha(alpha)
+        h.start(x0 if x0.ndim == 1 else x0[:, ch])
+        h.set_mean_epsilon(-eps)
+        h.set_leapfrog(leap)
+        h.run(steps)
+        s = h.scalars
+        assert np.array_equal(h.accepted, q[:, ch]), f"chain {ch}: positions differ"
+        assert np.array_equal(h.momentum, m[:, ch]), f"chain {ch}: momenta differ"
+        assert -s["accepted_potential"] == logl[ch]
+        assert s["current_acceptance"] == e.lane("acceptance")[ch]
+        assert s["last_accept"] == e.lane("last_accept")[ch]
+        assert s["step_count"] == e.lane("trials")[ch] == steps
+    return e
+
+
+@pytest.mark.parametrize("dim,nchains", [(5, 70), (64, 65), (300, 64)])
+def test_hmc_iso_matches_reference_chain(gpu, oracle, dim, nchains):
+    e = _check(gpu, oracle, dim, nchains, 0, None, np.ones(dim), 0.1, 10, 12)
+    assert e.lane("naccept").sum() > 0
+
+
+@pytest.mark.parametrize("dim,nchains,leap", [(6, 70, 20), (200, 64, 8)])
+def test_hmc_rosenbrock_matches_reference_chain(gpu, oracle, dim, nchains, leap):
+    rng = np.random.default_rng(dim)
+    x0 = rng.uniform(0.9, 1.1, (dim, nchains))
+    _check(gpu, oracle, dim, nchains, 2, [100.0], x0, 0.004, leap, 8)
+
+
+@pytest.mark.parametrize("dim,nchains,leap", [(5, 70, 20), (100, 64, 20), (300, 64, 6)])
+def test_hmc_quadratic_form_matches_reference_chain(gpu, oracle, dim, nchains, leap):
+    """The D x D gradient contraction of TDummyLogLikelihood.H:34-42 (config 5's hot loop)."""
+    err = _spd(dim, dim)
+    _check(gpu, oracle, dim, nchains, 1, err, np.ones(dim), 0.05, leap, 6, alpha=0.3)
+
+
+def test_hmc_quadform_potential_close_to_reference_order(gpu, oracle):
+    """The engine folds -log L = 1/2 q^T (Error q) per row instead of the reference's single
+    D^2-term running sum: same value to rounding."""
+    dim = 40
+    err = _spd(dim, 1)
+    h1 = oracle.Hmc(dim, kind=1, params=err, seed=5)
+    h2 = oracle.Hmc(dim, kind=1, params=err, seed=5, potential_from_gradient=True)
+    for h in (h1, h2):
+        h.start(np.ones(dim)); h.set_mean_epsilon(-0.05); h.set_leapfrog(10); h.run(50)
+    assert np.array_equal(h1.accepted, h2.accepted)
+    assert abs(h1.scalars["accepted_potential"] - h2.scalars["accepted_potential"]) < 1e-11 * abs(h1.scalars["accepted_potential"])
+
+
+def test_hmc_needs_fixed_step(gpu):
+    e = gpu.HmcEngine(5, 10)
+    e.Start(np.zeros(5))
+    with pytest.raises(gpu.SmcmcError) as err:
+        e.Step(1)                    # fMeanEpsilon = 0.05 > 0 after Start: covariance-driven tuning is not on the device
+    assert err.value.status == 5
+
+
+def test_hmc_posterior_iso(gpu):
+    dim, n = 8, 4096
+    e = gpu.HmcEngine(dim, n, seed=3)
+    e.Start(np.zeros(dim)); e.SetMeanEpsilon(-0.25); e.SetLeapFrog(8)
+    e.Step(300)
+    q, _, _ = e.state()
+    assert np.max(np.abs(q.mean(axis=1))) < 0.08
+    assert np.max(np.abs(np.cov(q) - np.eye(dim))) < 0.12
+    assert e.lane("naccept").mean() / 300 > 0.8

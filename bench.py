@@ -48,6 +48,39 @@ def cpu_baseline(seconds=12.0):
                       f"oracle/oracle_core.h compiled gcc -O2 (no -march), {dt:.1f} s"}
 
 
+ESS_STEPS, ESS_STRIDE, ESS_CHAINS = 8192, 16, 512
+
+
+def measure_ess(eng, torch, dim):
+    """Effective samples per chain-step of the current (adapted) ensemble."""
+    slots = ESS_STEPS // ESS_STRIDE
+    npad, dpad = eng.nchains_padded, eng.dim_padded
+    sx = torch.empty((slots, dpad, npad), dtype=torch.float64, device="cuda")
+    sl = torch.empty((slots, npad), dtype=torch.float64, device="cuda")
+    eng.StepSave(ESS_STEPS, sx.data_ptr(), sl.data_ptr(), stride=ESS_STRIDE)
+    torch.cuda.synchronize()
+    nch = min(ESS_CHAINS, eng.nchains)
+    x = sx[:, :dim, :nch].cpu().numpy()                     # [slot][dim][chain]
+    del sx, sl
+    n = x.shape[0]
+    x = x - x.mean(axis=0, keepdims=True)
+    f = np.fft.rfft(x, n=2 * n, axis=0)
+    acov = np.fft.irfft(f * np.conj(f), axis=0)[:n].real    # [lag][dim][chain]
+    acov = acov.mean(axis=2)                                # pooled over chains
+    rho = acov / acov[0]
+    taus = []
+    for d in range(dim):
+        r = rho[:, d]
+        tau = 1.0
+        for k in range(1, n - 1, 2):                        # Geyer: sum pairs while positive
+            pair = r[k] + r[k + 1]
+            if pair < 0:
+                break
+            tau += 2.0 * pair
+        taus.append(tau)
+    return 1.0 / (max(taus) * ESS_STRIDE)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -57,6 +90,7 @@ def main():
     ap.add_argument("--window", type=int, default=WINDOW)
     ap.add_argument("--fast", action="store_true", help="fused multiply-add arithmetic (not the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ess", action="store_true", help="skip the ESS trace after the timed region")
     ap.add_argument("--frozen", action="store_true", help="diagnostic: frozen covariance, no moment fold")
     ap.add_argument("--dim", type=int, default=DIM, help="diagnostic: other dimension (not the headline)")
     args = ap.parse_args()
@@ -139,6 +173,17 @@ def main():
             and not args.fast and not args.frozen):
         traffic = json.load(open(pmc))["hbm_bytes_per_launch"]
 
+    # ESS per chain-step (outside the timed region): a trace of the adapted ensemble saved
+    # every ESS_STRIDE steps through the device-side save path, autocorrelation per dimension
+    # (definition of MakeAutocorrelation.C:127-148) averaged over a subset of chains, Geyer's
+    # initial positive sequence, minimum over dimensions.
+    ess_per_chain_step = None
+    if rank == 0 and not args.no_ess:
+        try:
+            ess_per_chain_step = measure_ess(eng, torch, dim)
+        except Exception as exc:   # a diagnostic, never a reason to lose the bench line
+            print("ESS measurement skipped: %r" % (exc,), file=sys.stderr)
+
     naccept = eng.lane("naccept").astype(np.float64)
     total_steps = eng.get_param("TOTAL_STEPS")
     out = {
@@ -151,6 +196,8 @@ def main():
                    "dim": dim, "mode": "frozen" if args.frozen else "pooled", "chains_per_gpu": args.chains, "window": args.window,
                    "arithmetic": "fused" if args.fast else "reference-order", "seed": 20240607},
         "accept_rate": float(naccept.sum() / (total_steps * args.chains)),
+        "ess_per_chain_step": ess_per_chain_step,
+        "ess_per_s": (ess_per_chain_step * value) if ess_per_chain_step else None,
         "mean_sigma": float(eng.lane("sigma").mean()),
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,

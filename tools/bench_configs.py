@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Timing of the non-headline BASELINE configs (3, 4 per-GPU share, 5) on one GPU.
+Not the bench.py contract: a helper whose numbers go to profiles/*_notes.md."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+from smcmc_amd_loader import load_package  # noqa: E402
+
+pkg = load_package()
+
+
+def timed(fn, reps):
+    fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
+out = {}
+# config 3: Rosenbrock D=200, 16 384 chains (frozen covariance)
+e = pkg.Engine(200, 16384, likelihood=pkg.LIKE_ROSENBROCK, likelihood_params=[100.0], mode=pkg.MODE_FROZEN)
+rng = np.random.default_rng(0)
+e.Start(rng.uniform(0.5, 1.5, (200, 16384)))
+dt = timed(lambda: e.Step(32), 3)
+out["config3_rosenbrock_d200_16384_frozen"] = {"chain_steps_per_s": 16384 * 32 / dt, "ms_per_step": dt / 32 * 1e3}
+# config 4, one GPU's share: iso D=500, 32 768 chains (frozen covariance)
+e = pkg.Engine(500, 32768, mode=pkg.MODE_FROZEN)
+e.Start(np.zeros(500))
+dt = timed(lambda: e.Step(16), 3)
+out["config4_iso_d500_32768_frozen"] = {"chain_steps_per_s": 32768 * 16 / dt, "ms_per_step": dt / 16 * 1e3}
+# config 5: HMC, header TDummy D=500 (Error from Init()), 8 192 chains x 20 leapfrog steps
+from oracle import oracle as O  # noqa: E402  (only for TDummyLogLikelihood::Init's Error matrix)
+err = O.dummy_error_matrix(500)[1]
+h = pkg.HmcEngine(500, 8192, likelihood=pkg.LIKE_QUADFORM, likelihood_params=err)
+h.Start(np.ones(500)); h.SetMeanEpsilon(-0.0005); h.SetLeapFrog(20)
+dt = timed(lambda: h.Step(2), 2)
+out["config5_hmc_quadform_d500_8192_L20"] = {"trajectories_per_s": 8192 * 2 / dt, "ms_per_step": dt / 2 * 1e3,
+                                             "gradient_GFLOPs": 8192 * 2 / dt * 21 * 2 * 500 * 500 / 1e9,
+                                             "accept": float(h.lane("naccept").mean() / h.lane("trials").mean())}
+print(json.dumps(out, indent=1))

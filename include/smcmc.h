@@ -73,6 +73,8 @@ typedef enum {
     SMCMC_P_UPDATE_COUNT = 15,          /* number of UpdateProposal calls (diagnostic, read only) */
     SMCMC_P_LAST_UPDATE_PATH = 16,      /* 0 Cholesky 1 conditioned 2 eigen 3 emergency 4 reset (read only) */
     SMCMC_P_EXACT_ARITHMETIC = 17,      /* 1: reference operation order (default); 0: fused multiply-add */
+    SMCMC_P_MOMENT_STRIDE = 18,         /* POOLED, dim > 63: fold the current point into the pooled moments every n-th step (default 1) */
+    SMCMC_P_MOMENT_GROUP = 19,          /* chains per moment group (read only: 64, or the slice size of the dim > 63 path) */
     SMCMC_P_COUNT_
 } smcmc_param;
 

@@ -57,6 +57,8 @@ typedef struct {
     int step_rms_window;
     /* moments */
     int ngroups;
+    int moment_group;          /* chains per moment group: 64, or the slice size of the dim > 63 path */
+    int moment_stride;         /* fold the point seen at the start of step t when (t-1) % stride == 0 */
     double* acc;               /* [group][packed (D+1)(D+2)/2] */
     double* c0;                /* centre the moments are taken about */
     /* pending per-lane adjustments from the last pooled update */
@@ -97,6 +99,8 @@ oracle_ensemble* oracle_ensemble_create(int nchains, int dim, int like_kind, con
     e->last_accept = (uint8_t*)calloc(n, sizeof(uint8_t));
     e->last_logl_proposed = (double*)calloc(n, sizeof(double));
     e->step_rms_window = 1000;
+    e->moment_group = 64;
+    e->moment_stride = 1;
     e->ngroups = (nchains + 63) / 64;
     e->acc = (double*)calloc((size_t)e->ngroups * (size_t)ens_npacked(dim), sizeof(double));
     e->c0 = (double*)calloc(d, sizeof(double));
@@ -113,6 +117,15 @@ void oracle_ensemble_destroy(oracle_ensemble* e) {
     free(e->next_update); free(e->last_value); free(e->last_x0); free(e->step_rms);
     free(e->step_rms_trials); free(e->naccept); free(e->last_accept); free(e->last_logl_proposed);
     free(e->acc); free(e->c0); free(e);
+}
+
+/* moment grouping of the large-dimension HIP path (before start) */
+void oracle_ensemble_set_moment_grouping(oracle_ensemble* e, int group_chains, int stride) {
+    e->moment_group = group_chains;
+    e->moment_stride = stride;
+    e->ngroups = (e->nchains + group_chains - 1) / group_chains;
+    free(e->acc);
+    e->acc = (double*)calloc((size_t)e->ngroups * (size_t)ens_npacked(e->dim), sizeof(double));
 }
 
 /* shared-proposal setters (before start) */
@@ -228,8 +241,10 @@ static void ens_step_once(oracle_ensemble* e, int metropolis) {
                                              &e->acceptance_trials[c], P->acceptance_window,
                                              &e->rigidity[c], P->target, &e->sigma[c], moved);
         /* --- pooled moments of the current point --- */
-        if (e->mode == ENS_MODE_POOLED) {
-            double* acc = e->acc + (size_t)(c / 64) * (size_t)npk;
+        if (e->mode == ENS_MODE_POOLED && ((e->total_steps - 1) % e->moment_stride) != 0) {
+            /* not a fold step */
+        } else if (e->mode == ENS_MODE_POOLED) {
+            double* acc = e->acc + (size_t)(c / e->moment_group) * (size_t)npk;
             for (int d = 0; d < D; ++d) y[d] = x[d] - e->c0[d];
             y[D] = 1.0;
             for (int i = 0; i <= D; ++i)

@@ -16,6 +16,7 @@
 #include "smcmc.h"
 #include "smcmc_kernels.hip.h"
 #include "smcmc_panel_kernel.hip.h"
+#include "smcmc_fold_kernel.hip.h"
 #include "smcmc_proposal.hpp"
 
 using namespace smcmc;
@@ -63,6 +64,8 @@ int tiles_for(int dp) {
 
 struct smcmc_engine {
     int dim = 0, nchains = 0, npad = 0, ngroups = 0, dp = 0, nt = 0;
+    int moment_stride = 1;   // large-dimension path: fold the current point every moment_stride-th step
+    int slice_chains = 0;    // large-dimension path: chains per moment group (kFoldSlices groups)
     int panel_w = 0;   // 0: register-resident kernels (dim <= 63); 4 / 8: wavefronts per chain group of the panel kernel
     int likelihood = 0, mode = SMCMC_MODE_POOLED, device = 0;
     bool exact = true, started = false;
@@ -119,6 +122,16 @@ int status_of(smcmc_engine* h, UpdateStatus st) {
 
 size_t npacked(const smcmc_engine* h) { return (size_t)(h->dim + 1) * (h->dim + 2) / 2; }
 
+// doubles of the moment accumulators: per 64-chain group for the register kernels, per
+// (slice, 16x16 tile) for the large-dimension fold kernel
+size_t gacc_doubles(const smcmc_engine* h) {
+    if (h->panel_w) {
+        const size_t T = (size_t)(h->dim + 1 + 15) / 16;
+        return (size_t)kFoldSlices * (T * (T + 1) / 2) * 4 * kWave;
+    }
+    return (size_t)h->ngroups * h->nt * 4 * kWave;
+}
+
 // decomposition (and, for QUADFORM, the Error matrix) zero-padded to [dp][dp]
 int upload_padded(smcmc_engine* h, const double* src, double* dst_dev) {
     const int D = h->dim, DP = h->dp;
@@ -142,6 +155,8 @@ int upload_shared(smcmc_engine* h) {
                     if (j < D) perm[((size_t)w * D + i) * kPanelCW + jl] = h->prop->decomp[(size_t)i * D + j];
                 }
         HIP_TRY(h, hipMemcpyAsync(h->d_U, perm.data(), perm.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(h->d_c0, h->prop->centre.data(), (size_t)D * sizeof(double), hipMemcpyHostToDevice,
+                                  h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
         return SMCMC_OK;
     }
@@ -220,24 +235,45 @@ int launch(smcmc_engine* h, int nsteps, int metropolis, int stride, double* save
         p.save_x = save_x; p.save_logl = save_logl; p.save_stride = stride;
     }
     if (h->panel_w) {
-        if (h->mode == SMCMC_MODE_POOLED)
-            return fail(h, SMCMC_ERR_UNSUPPORTED, "pooled covariance for dim > 63 is not on the HIP path yet");
         PanelParams q;
         std::memset(&q, 0, sizeof(q));
-        q.nchains = p.nchains; q.npad = p.npad; q.dim = p.dim; q.nsteps = p.nsteps; q.metropolis = p.metropolis;
-        q.step0 = p.step0; q.chain_offset = p.chain_offset; q.seed = p.seed;
+        q.nchains = p.nchains; q.npad = p.npad; q.dim = p.dim; q.metropolis = p.metropolis;
+        q.chain_offset = p.chain_offset; q.seed = p.seed;
         q.Uperm = h->d_U; q.like = h->d_like;
         q.target = p.target; q.acc_window = p.acc_window; q.asig = p.asig; q.max_up = p.max_up;
         q.acc_w = p.acc_w; q.acc_wW = p.acc_wW; q.pending_sigma_scale = p.pending_sigma_scale;
         q.pending_deweight = p.pending_deweight; q.per_lane_update = p.per_lane_update;
         q.step_rms_window = p.step_rms_window; q.full_u = h->prop->decompFull ? 1 : 0;
         q.x = p.x; q.lane_f64 = p.lane_f64; q.lane_i32 = p.lane_i32;
-        q.save_x = p.save_x; q.save_logl = p.save_logl; q.save_stride = p.save_stride;
+        q.save_stride = 1;
         const bool exact = h->exact || h->prop->decompFull;
-        hipError_t e = (h->panel_w == 4) ? launch_panel<4, kPanelCW>(q, h->likelihood, exact, h->stream)
-                                         : launch_panel<8, kPanelCW>(q, h->likelihood, exact, h->stream);
-        if (e != hipSuccess) return fail(h, SMCMC_ERR_HIP, std::string("panel kernel launch: ") + hipGetErrorString(e));
-        h->total_steps += (uint32_t)nsteps;
+        const bool pooled = (h->mode == SMCMC_MODE_POOLED);
+        if (pooled && save_x) return fail(h, SMCMC_ERR_UNSUPPORTED, "saving inside a pooled large-dimension launch");
+        if (!pooled) { q.save_x = p.save_x; q.save_logl = p.save_logl; q.save_stride = p.save_stride; }
+        // POOLED: the point UpdateState sees at the start of step t is folded into the moments
+        // when (t - 1) % moment_stride == 0; the step launches are cut at those steps
+        int done = 0;
+        while (done < nsteps) {
+            int seg = nsteps - done;
+            if (pooled) {
+                const int phase = (int)(h->total_steps % (uint32_t)h->moment_stride);
+                if (phase == 0) {
+                    hipError_t e = launch_fold(h->d_x, h->d_c0, h->nchains, h->npad, h->dim, h->slice_chains, h->d_gacc,
+                                               h->stream);
+                    if (e != hipSuccess) return fail(h, SMCMC_ERR_HIP, std::string("fold kernel launch: ") + hipGetErrorString(e));
+                }
+                seg = std::min(seg, h->moment_stride - phase);
+            }
+            q.nsteps = seg;
+            q.step0 = h->total_steps;
+            hipError_t e = (h->panel_w == 4) ? launch_panel<4, kPanelCW>(q, h->likelihood, exact, h->stream)
+                                             : launch_panel<8, kPanelCW>(q, h->likelihood, exact, h->stream);
+            if (e != hipSuccess) return fail(h, SMCMC_ERR_HIP, std::string("panel kernel launch: ") + hipGetErrorString(e));
+            h->total_steps += (uint32_t)seg;
+            done += seg;
+            q.pending_sigma_scale = 1.0;
+            q.pending_deweight = 0;
+        }
         h->pending_sigma_scale = 1.0;
         h->pending_deweight = 0;
         return SMCMC_OK;
@@ -305,6 +341,7 @@ int smcmc_create(int dim, int nchains, int likelihood, uint64_t seed, uint32_t c
     h->npad = (nchains + kWave - 1) / kWave * kWave;
     h->ngroups = h->npad / kWave;
     h->nt = panel_w ? 1 : tiles_for(dp);
+    h->slice_chains = ((h->ngroups + kFoldSlices - 1) / kFoldSlices) * kWave;
     h->prop = new SharedProposal(dim);
     *out = h;
     HIP_TRY(h, hipSetDevice(device));
@@ -318,7 +355,7 @@ int smcmc_create(int dim, int nchains, int likelihood, uint64_t seed, uint32_t c
     HIP_TRY(h, hipMemset(h->d_U, 0, sizeof(double) * u_doubles));
     HIP_TRY(h, hipMalloc(&h->d_like, sizeof(double) * dp * dp));
     HIP_TRY(h, hipMalloc(&h->d_c0, sizeof(double) * dp));
-    HIP_TRY(h, hipMalloc(&h->d_gacc, sizeof(double) * (size_t)h->ngroups * h->nt * 4 * kWave));
+    HIP_TRY(h, hipMalloc(&h->d_gacc, sizeof(double) * gacc_doubles(h)));
     HIP_TRY(h, hipMalloc(&h->d_moments, sizeof(double) * npacked(h)));
     HIP_TRY(h, hipMalloc(&h->d_chunks, sizeof(double) * npacked(h) * ((h->ngroups + kReduceChunk - 1) / kReduceChunk)));
     HIP_TRY(h, hipMemset(h->d_x, 0, sizeof(double) * np * dp));
@@ -327,7 +364,7 @@ int smcmc_create(int dim, int nchains, int likelihood, uint64_t seed, uint32_t c
     HIP_TRY(h, hipMemset(h->d_lane_i32, 0, sizeof(int32_t) * np * SMCMC_LANE_I32_COUNT_));
     HIP_TRY(h, hipMemset(h->d_like, 0, sizeof(double) * dp * dp));
     HIP_TRY(h, hipMemset(h->d_c0, 0, sizeof(double) * dp));
-    HIP_TRY(h, hipMemset(h->d_gacc, 0, sizeof(double) * (size_t)h->ngroups * h->nt * 4 * kWave));
+    HIP_TRY(h, hipMemset(h->d_gacc, 0, sizeof(double) * gacc_doubles(h)));
     HIP_TRY(h, hipMemset(h->d_moments, 0, sizeof(double) * npacked(h)));
     return SMCMC_OK;
 }
@@ -439,6 +476,12 @@ int smcmc_set_param(smcmc_engine* h, int which, double v) {
         case SMCMC_P_COVARIANCE_TRIALS: P.covTrials = v; return SMCMC_OK;
         case SMCMC_P_CENTER_TRIALS: P.centreTrials = v; return SMCMC_OK;
         case SMCMC_P_EXACT_ARITHMETIC: h->exact = (v != 0.0); return SMCMC_OK;
+        case SMCMC_P_MOMENT_STRIDE:
+            if (v < 1.0) return fail(h, SMCMC_ERR_INVALID, "moment stride must be >= 1");
+            if (!h->panel_w && v != 1.0)
+                return fail(h, SMCMC_ERR_UNSUPPORTED, "the register-resident kernels fold every step");
+            h->moment_stride = (int)v;
+            return SMCMC_OK;
         default: return fail(h, SMCMC_ERR_INVALID, "parameter is read only or unknown");
     }
 }
@@ -471,6 +514,8 @@ int smcmc_get_param(smcmc_engine* h, int which, double* out) {
         case SMCMC_P_UPDATE_COUNT: *out = P.updateCount; break;
         case SMCMC_P_LAST_UPDATE_PATH: *out = P.lastPath; break;
         case SMCMC_P_EXACT_ARITHMETIC: *out = h->exact ? 1.0 : 0.0; break;
+        case SMCMC_P_MOMENT_STRIDE: *out = h->moment_stride; break;
+        case SMCMC_P_MOMENT_GROUP: *out = h->panel_w ? h->slice_chains : kWave; break;
         default: return fail(h, SMCMC_ERR_INVALID, "unknown parameter");
     }
     return SMCMC_OK;
@@ -494,7 +539,7 @@ int smcmc_start(smcmc_engine* h, const double* x0, int broadcast) {
     HIP_TRY(h, hipMemcpyAsync(h->d_forced, x.data(), x.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemsetAsync(h->d_lane_f64, 0, sizeof(double) * NP * SMCMC_LANE_F64_COUNT_, h->stream));
     HIP_TRY(h, hipMemsetAsync(h->d_lane_i32, 0, sizeof(int32_t) * NP * SMCMC_LANE_I32_COUNT_, h->stream));
-    HIP_TRY(h, hipMemsetAsync(h->d_gacc, 0, sizeof(double) * (size_t)h->ngroups * h->nt * 4 * kWave, h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->d_gacc, 0, sizeof(double) * gacc_doubles(h), h->stream));
     if (h->panel_w) {
         hipError_t e = launch_start_loglike(h->d_x, N, NP, D, h->d_like, h->d_lane_f64 + (size_t)SMCMC_LANE_LOGL * NP,
                                             h->likelihood, h->exact, h->stream);
@@ -545,7 +590,7 @@ int smcmc_start(smcmc_engine* h, const double* x0, int broadcast) {
     }
     HIP_TRY(h, hipMemcpyAsync(h->d_lane_f64, lf.data(), lf.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->d_lane_i32, li.data(), li.size() * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipMemsetAsync(h->d_gacc, 0, sizeof(double) * (size_t)h->ngroups * h->nt * 4 * kWave, h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->d_gacc, 0, sizeof(double) * gacc_doubles(h), h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     st = upload_shared(h);
     if (st) return st;
@@ -584,10 +629,15 @@ int smcmc_moments_size(const smcmc_engine* h) { return h ? (int)npacked(h) : 0; 
 
 int smcmc_reduce_moments(smcmc_engine* h) {
     if (!h || !h->started) return SMCMC_ERR_INVALID;
-    if (h->panel_w) return fail(h, SMCMC_ERR_UNSUPPORTED, "pooled covariance for dim > 63 is not on the HIP path yet");
+    if (h->panel_w) {
+        hipError_t e = launch_fold_reduce(h->d_gacc, h->dim, h->d_moments, h->stream);
+        if (e != hipSuccess) return fail(h, SMCMC_ERR_HIP, std::string("fold reduce launch: ") + hipGetErrorString(e));
+        HIP_TRY(h, hipMemsetAsync(h->d_gacc, 0, sizeof(double) * gacc_doubles(h), h->stream));
+        return SMCMC_OK;
+    }
     hipError_t e = dispatch_reduce(h->dp, h->d_gacc, h->ngroups, h->dim, h->d_chunks, h->d_moments, h->stream);
     if (e != hipSuccess) return fail(h, SMCMC_ERR_HIP, std::string("reduce kernel launch: ") + hipGetErrorString(e));
-    HIP_TRY(h, hipMemsetAsync(h->d_gacc, 0, sizeof(double) * (size_t)h->ngroups * h->nt * 4 * kWave, h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->d_gacc, 0, sizeof(double) * gacc_doubles(h), h->stream));
     return SMCMC_OK;
 }
 
@@ -667,7 +717,7 @@ int smcmc_reset_proposal(smcmc_engine* h) {
     st = broadcast_lane_i32(h, SMCMC_LANE_NEXT_UPDATE, P.nextUpdate); if (st) return st;
     st = broadcast_lane_f64(h, SMCMC_LANE_ACCEPTANCE, P.acceptance); if (st) return st;
     st = broadcast_lane_f64(h, SMCMC_LANE_ACCEPTANCE_TRIALS, P.acceptanceTrials); if (st) return st;
-    HIP_TRY(h, hipMemsetAsync(h->d_gacc, 0, sizeof(double) * (size_t)h->ngroups * h->nt * 4 * kWave, h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->d_gacc, 0, sizeof(double) * gacc_doubles(h), h->stream));
     h->pending_sigma_scale = 1.0;
     h->pending_deweight = 0;
     return upload_shared(h);

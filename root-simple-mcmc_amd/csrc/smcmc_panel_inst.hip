@@ -1,6 +1,7 @@
 // smcmc_panel_inst.hip -- instantiations of the large-dimension step kernel for one
 // workgroup shape; built once per -DSMCMC_PANEL_W=<wavefronts per chain group>.
 #include "smcmc_panel_kernel.hip.h"
+#include "smcmc_fold_kernel.hip.h"
 
 #ifndef SMCMC_PANEL_W
 #error "compile with -DSMCMC_PANEL_W=<4|8>"
@@ -30,6 +31,22 @@ hipError_t launch_panel<SMCMC_PANEL_W, kPanelCW>(const PanelParams& p, int like,
 }
 
 #if SMCMC_PANEL_W == 4
+hipError_t launch_fold(const double* x, const double* c0, int nchains, int npad, int D, int slice_chains,
+                       double* gacc, hipStream_t s) {
+    const int T = (D + 1 + 15) / 16, ntiles = T * (T + 1) / 2;
+    hipLaunchKernelGGL(fold_moments_kernel, dim3(ntiles, kFoldSlices), dim3(kWave), 0, s, x, c0, nchains, npad, D,
+                       slice_chains, gacc);
+    return hipGetLastError();
+}
+
+hipError_t launch_fold_reduce(const double* gacc, int D, double* moments, hipStream_t s) {
+    const int T = (D + 1 + 15) / 16, ntiles = T * (T + 1) / 2;
+    const int npk = (D + 1) * (D + 2) / 2;
+    hipLaunchKernelGGL(fold_reduce_kernel, dim3((npk + 255) / 256), dim3(256), 0, s, gacc, ntiles, kFoldSlices, D,
+                       moments);
+    return hipGetLastError();
+}
+
 hipError_t launch_start_loglike(const double* x, int nchains, size_t npad, int D, const double* like_params,
                                 double* logl_out, int like, bool exact, hipStream_t s) {
     const dim3 grid((nchains + 255) / 256), block(256);

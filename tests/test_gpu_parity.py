@@ -307,3 +307,23 @@ def test_frozen_large_dim_matches_oracle(gpu, oracle, kind, dim, nchains, steps,
     _assert_same_state(e, o, "after 1 step")
     e.Step(steps - 1); o.step(steps - 1)
     _assert_same_state(e, o, f"after {steps} steps")
+
+
+@pytest.mark.parametrize("dim,nchains,stride,window,nwin", [(100, 256, 1, 6, 3), (200, 192, 4, 8, 2), (300, 640, 3, 6, 2)])
+def test_pooled_large_dim_matches_oracle(gpu, oracle, dim, nchains, stride, window, nwin):
+    """Pooled covariance for D > 63: the moment fold runs as its own kernel (one wavefront
+    per 16x16 tile and chain slice) every `stride`-th step; still bit for bit the oracle."""
+    e, o = _pair(gpu, oracle, dim, nchains, 0, gpu.MODE_POOLED, True)
+    e.set_param("MOMENT_STRIDE", stride)
+    o.set_moment_grouping(int(e.get_param("MOMENT_GROUP")), stride)
+    assert e.Start(np.zeros(dim)) and o.start(np.zeros(dim))
+    for w in range(nwin):
+        e.Step(window); o.step(window)
+        _assert_same_state(e, o, f"window {w}")
+        e.reduce_moments()
+        m_gpu, m_cpu = e.read_moments(), o.reduce_moments()
+        assert np.array_equal(m_gpu, m_cpu), f"window {w}: moments differ"
+        e.apply_moments(); o.apply_moments(m_cpu)
+        assert np.array_equal(e.decomposition, o.decomposition)
+    e.Step(2); o.step(2)
+    _assert_same_state(e, o, "after the last sync")

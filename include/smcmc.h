@@ -125,6 +125,9 @@ int smcmc_set_likelihood_params(smcmc_engine* h, const double* params, int count
 int smcmc_set_mode(smcmc_engine* h, int mode);
 int smcmc_set_gaussian(smcmc_engine* h, int dim, double sigma);                      /* SetGaussian :855 */
 int smcmc_set_uniform(smcmc_engine* h, int dim, double minimum, double maximum);     /* SetUniform :833 */
+/* SetScanDimension (TSimpleMCMC.H:820-830): while set, a step redraws only that dimension (about the
+ * estimated centre, or uniformly) and leaves the proposal state alone; out of range = off. */
+int smcmc_set_scan_dimension(smcmc_engine* h, int dim);
 int smcmc_set_correlation(smcmc_engine* h, int dim1, int dim2, double correlation);  /* SetCorrelation :883 */
 int smcmc_reset_correlations(smcmc_engine* h);                                       /* ResetCorrelations :874 */
 int smcmc_set_param(smcmc_engine* h, int which, double value);

@@ -44,6 +44,7 @@ SIGNATURES = {
     "smcmc_set_mode": (C.c_int, [_H, C.c_int]),
     "smcmc_set_gaussian": (C.c_int, [_H, C.c_int, C.c_double]),
     "smcmc_set_uniform": (C.c_int, [_H, C.c_int, C.c_double, C.c_double]),
+    "smcmc_set_scan_dimension": (C.c_int, [_H, C.c_int]),
     "smcmc_set_correlation": (C.c_int, [_H, C.c_int, C.c_int, C.c_double]),
     "smcmc_reset_correlations": (C.c_int, [_H]),
     "smcmc_set_param": (C.c_int, [_H, C.c_int, C.c_double]),

@@ -37,8 +37,9 @@ int pick_dp(int dim) {
 
 hipError_t dispatch_step(int dp, const StepParams& p, int like, bool exact, bool fullu, bool moments,
                          hipStream_t s) {
+    const bool special = p.scan_dim >= 0 || p.uniform_mask != 0;
     switch (dp) {
-#define SMCMC_DP_CASE(n) case n: return launch_step<n>(p, like, exact, fullu, moments, s);
+#define SMCMC_DP_CASE(n) case n: return launch_step<n>(p, like, exact, fullu, moments, special, s);
         SMCMC_FOR_EACH_DP(SMCMC_DP_CASE)
 #undef SMCMC_DP_CASE
         default: return hipErrorInvalidValue;
@@ -91,6 +92,8 @@ struct smcmc_engine {
     double* d_moments = nullptr;
     double* d_chunks = nullptr;
     double* d_forced = nullptr;
+    double* d_uniform = nullptr;   // [2][dp] bounds of the uniform dimensions
+    int scan_dim = -1;             // fScanDimension
     std::string error;
 };
 
@@ -160,8 +163,19 @@ int upload_shared(smcmc_engine* h) {
         HIP_TRY(h, hipStreamSynchronize(h->stream));
         return SMCMC_OK;
     }
-    int st = upload_padded(h, h->prop->decomp.data(), h->d_U);
+    // Dimensions with a uniform proposal take no part in the Gaussian step
+    // (TSimpleMCMC.H:711-716, 721): their rows and columns of the device copy are zero.
+    std::vector<double> U(h->prop->decomp);
+    std::vector<double> bounds((size_t)2 * h->dp, 0.0);
+    for (int i = 0; i < h->dim; ++i) {
+        if (h->prop->ptype[i] != 1) continue;
+        for (int j = 0; j < h->dim; ++j) U[(size_t)i * h->dim + j] = U[(size_t)j * h->dim + i] = 0.0;
+        bounds[i] = h->prop->param1[i];
+        bounds[h->dp + i] = h->prop->param2[i];
+    }
+    int st = upload_padded(h, U.data(), h->d_U);
     if (st) return st;
+    HIP_TRY(h, hipMemcpyAsync(h->d_uniform, bounds.data(), bounds.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
     std::vector<double> c0(h->dp, 0.0);
     for (int d = 0; d < h->dim; ++d) c0[d] = h->prop->centre[d];
     HIP_TRY(h, hipMemcpyAsync(h->d_c0, c0.data(), c0.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -221,6 +235,21 @@ StepParams make_params(smcmc_engine* h, int nsteps, int metropolis) {
     p.x = h->d_x; p.lane_f64 = h->d_lane_f64; p.lane_i32 = h->d_lane_i32;
     p.gacc = h->d_gacc;
     p.save_x = nullptr; p.save_logl = nullptr; p.save_stride = 1;
+    p.uniform = h->d_uniform;
+    for (int d = 0; d < h->dim; ++d)
+        if (P.ptype[d] == 1) p.uniform_mask |= (uint64_t)1 << d;
+    p.scan_dim = h->scan_dim;
+    if (h->scan_dim >= 0) {
+        const int sd = h->scan_dim;
+        if (P.ptype[sd] == 1) {
+            p.scan_uniform = 1; p.scan_a = P.param1[sd]; p.scan_b = P.param2[sd];
+        } else {
+            // Gaussian about the estimated centre (TSimpleMCMC.H:696-701); the centre is the
+            // ensemble's shared estimate
+            p.scan_a = P.centre[sd];
+            p.scan_b = (P.param1[sd] > 0) ? std::sqrt(P.param1[sd]) : 1.0;
+        }
+    }
     return p;
 }
 
@@ -281,6 +310,9 @@ int launch(smcmc_engine* h, int nsteps, int metropolis, int stride, double* save
     const bool moments = (h->mode == SMCMC_MODE_POOLED);
     const bool fullu = h->prop->decompFull;
     const bool exact = h->exact || fullu;   // the full (eigen) decomposition only exists in reference order
+    if ((p.scan_dim >= 0 || p.uniform_mask != 0) && !exact)
+        return fail(h, SMCMC_ERR_UNSUPPORTED,
+                    "uniform proposals and the scan of a dimension run in reference-order arithmetic only");
     hipError_t e = dispatch_step(h->dp, p, h->likelihood, exact, fullu, moments, h->stream);
     if (e != hipSuccess) return fail(h, SMCMC_ERR_HIP, std::string("step kernel launch: ") + hipGetErrorString(e));
     h->total_steps += (uint32_t)nsteps;
@@ -360,6 +392,8 @@ int smcmc_create(int dim, int nchains, int likelihood, uint64_t seed, uint32_t c
     HIP_TRY(h, hipMalloc(&h->d_chunks, sizeof(double) * npacked(h) * ((h->ngroups + kReduceChunk - 1) / kReduceChunk)));
     HIP_TRY(h, hipMemset(h->d_x, 0, sizeof(double) * np * dp));
     HIP_TRY(h, hipMemset(h->d_forced, 0, sizeof(double) * np * dp));
+    HIP_TRY(h, hipMalloc(&h->d_uniform, sizeof(double) * 2 * dp));
+    HIP_TRY(h, hipMemset(h->d_uniform, 0, sizeof(double) * 2 * dp));
     HIP_TRY(h, hipMemset(h->d_lane_f64, 0, sizeof(double) * np * SMCMC_LANE_F64_COUNT_));
     HIP_TRY(h, hipMemset(h->d_lane_i32, 0, sizeof(int32_t) * np * SMCMC_LANE_I32_COUNT_));
     HIP_TRY(h, hipMemset(h->d_like, 0, sizeof(double) * dp * dp));
@@ -375,7 +409,7 @@ int smcmc_destroy(smcmc_engine* h) {
         (void)hipSetDevice(h->device);
         (void)hipStreamSynchronize(h->stream);
     }
-    (void)hipFree(h->d_x); (void)hipFree(h->d_forced); (void)hipFree(h->d_lane_f64); (void)hipFree(h->d_lane_i32);
+    (void)hipFree(h->d_x); (void)hipFree(h->d_forced); (void)hipFree(h->d_uniform); (void)hipFree(h->d_lane_f64); (void)hipFree(h->d_lane_i32);
     (void)hipFree(h->d_U); (void)hipFree(h->d_like); (void)hipFree(h->d_c0); (void)hipFree(h->d_gacc);
     (void)hipFree(h->d_moments); (void)hipFree(h->d_chunks);
     delete h->prop;
@@ -406,16 +440,28 @@ int smcmc_set_mode(smcmc_engine* h, int mode) {
 int smcmc_set_gaussian(smcmc_engine* h, int dim, double sigma) {
     if (!h) return SMCMC_ERR_INVALID;
     if (dim < 0 || dim >= h->dim) return fail(h, SMCMC_ERR_INVALID, "Dimension is out of range.");   // :856-860
+    const bool was_uniform = h->prop->ptype[dim] == 1;
     h->prop->ptype[dim] = 0;
     h->prop->param1[dim] = sigma * sigma;
-    return SMCMC_OK;
+    return (h->started && was_uniform) ? upload_shared(h) : SMCMC_OK;
 }
 
 int smcmc_set_uniform(smcmc_engine* h, int dim, double minimum, double maximum) {
     if (!h) return SMCMC_ERR_INVALID;
     if (dim < 0 || dim >= h->dim) return fail(h, SMCMC_ERR_INVALID, "Dimension is out of range.");
-    (void)minimum; (void)maximum;
-    return fail(h, SMCMC_ERR_UNSUPPORTED, "uniform per-dimension proposals are not on the HIP path yet");
+    if (h->panel_w) return fail(h, SMCMC_ERR_UNSUPPORTED, "uniform per-dimension proposals for dim > 63 are not on the HIP path yet");
+    h->prop->ptype[dim] = 1;                                                                        // :845-847
+    h->prop->param1[dim] = minimum;
+    h->prop->param2[dim] = maximum;
+    return h->started ? upload_shared(h) : SMCMC_OK;
+}
+
+int smcmc_set_scan_dimension(smcmc_engine* h, int dim) {
+    if (!h) return SMCMC_ERR_INVALID;
+    if (h->panel_w && dim >= 0 && dim < h->dim)
+        return fail(h, SMCMC_ERR_UNSUPPORTED, "scan of a dimension for dim > 63 is not on the HIP path yet");
+    h->scan_dim = (dim < 0 || dim >= h->dim) ? -1 : dim;                                            // :827-829
+    return SMCMC_OK;
 }
 
 int smcmc_set_correlation(smcmc_engine* h, int d1, int d2, double c) {
@@ -556,6 +602,7 @@ int smcmc_start(smcmc_engine* h, const double* x0, int broadcast) {
         p.has_forced = 1; p.forced = h->d_forced;
         p.x = h->d_x; p.lane_f64 = h->d_lane_f64; p.lane_i32 = h->d_lane_i32; p.gacc = h->d_gacc;
         p.save_stride = 1;
+        p.scan_dim = -1;
         hipError_t e = dispatch_step(h->dp, p, h->likelihood, h->exact, false, false, h->stream);
         if (e != hipSuccess) return fail(h, SMCMC_ERR_HIP, std::string("start kernel launch: ") + hipGetErrorString(e));
     }

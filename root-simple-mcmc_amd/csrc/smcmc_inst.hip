@@ -9,20 +9,26 @@
 
 namespace smcmc {
 
-template <int DP, int LIKE, bool EXACT, bool FULLU, bool MOM>
+template <int DP, int LIKE, bool EXACT, bool FULLU, bool MOM, bool SPECIAL>
 static hipError_t go(const StepParams& p, hipStream_t s) {
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(step_kernel<DP, LIKE, EXACT, FULLU, MOM>), dim3(p.npad / kWave),
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(step_kernel<DP, LIKE, EXACT, FULLU, MOM, SPECIAL>), dim3(p.npad / kWave),
                        dim3(kWave), 0, s, p);
     return hipGetLastError();
 }
 
 template <>
-hipError_t launch_step_like<SMCMC_DP, SMCMC_LIKE>(const StepParams& p, bool exact, bool fullu, bool mom,
+hipError_t launch_step_like<SMCMC_DP, SMCMC_LIKE>(const StepParams& p, bool exact, bool fullu, bool mom, bool special,
                                                   hipStream_t s) {
     constexpr int DP = SMCMC_DP, LIKE = SMCMC_LIKE;
-    if (fullu) return mom ? go<DP, LIKE, true, true, true>(p, s) : go<DP, LIKE, true, true, false>(p, s);
-    if (exact) return mom ? go<DP, LIKE, true, false, true>(p, s) : go<DP, LIKE, true, false, false>(p, s);
-    return mom ? go<DP, LIKE, false, false, true>(p, s) : go<DP, LIKE, false, false, false>(p, s);
+    if (special) {
+        // uniform dimensions / scan: reference-order arithmetic only
+        if (!exact) return hipErrorNotSupported;
+        if (fullu) return mom ? go<DP, LIKE, true, true, true, true>(p, s) : go<DP, LIKE, true, true, false, true>(p, s);
+        return mom ? go<DP, LIKE, true, false, true, true>(p, s) : go<DP, LIKE, true, false, false, true>(p, s);
+    }
+    if (fullu) return mom ? go<DP, LIKE, true, true, true, false>(p, s) : go<DP, LIKE, true, true, false, false>(p, s);
+    if (exact) return mom ? go<DP, LIKE, true, false, true, false>(p, s) : go<DP, LIKE, true, false, false, false>(p, s);
+    return mom ? go<DP, LIKE, false, false, true, false>(p, s) : go<DP, LIKE, false, false, false, false>(p, s);
 }
 
 #if SMCMC_LIKE == 0

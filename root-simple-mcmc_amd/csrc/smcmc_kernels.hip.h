@@ -169,6 +169,11 @@ struct StepParams {
     double* save_x;            // optional [slot][DP][npad]
     double* save_logl;         // optional [slot][npad]
     int save_stride;
+    uint64_t uniform_mask;     // bit d: dimension d has a uniform proposal (TSimpleMCMC.H:711-716)
+    const double* uniform;     // [2][DP]: lower bounds, upper bounds
+    int scan_dim;              // fScanDimension (TSimpleMCMC.H:685-704), -1 = off
+    int scan_uniform;          // the scanned dimension has a uniform proposal
+    double scan_a, scan_b;     // uniform: bounds; Gaussian: centre, sigma
     int zero;                  // always 0; makes table addresses depend on the step so that the
                                // compiler does not hoist (and then spill) whole tables out of the loop
 };
@@ -231,7 +236,9 @@ __device__ __forceinline__ double loglike(const double (&p)[DP], cptr_f64 prm, i
     return logl;
 }
 
-template <int DP, int LIKE, bool EXACT, bool FULLU, bool MOMENTS>
+// SPECIAL = the variant that also knows uniform per-dimension proposals and the scan of one
+// dimension (TSimpleMCMC.H:685-716); kept out of the common kernels, whose register allocation it disturbs.
+template <int DP, int LIKE, bool EXACT, bool FULLU, bool MOMENTS, bool SPECIAL>
 __global__ void __launch_bounds__(kWave, 2) step_kernel(const StepParams p) {
     constexpr int T = Geo<DP>::T;
     constexpr int NT = Geo<DP>::NT;
@@ -379,6 +386,30 @@ __global__ void __launch_bounds__(kWave, 2) step_kernel(const StepParams p) {
         s0 = 1;
     }
 
+    if (SPECIAL && p.scan_dim >= 0) {
+        // scan of one dimension (TSimpleMCMC.H:685-704): the proposal is the current point
+        // with that dimension redrawn; the proposal state is not updated
+        const uint32_t sd = (uint32_t)p.scan_dim;
+#pragma nounroll
+        for (int s = s0; s < p.nsteps; ++s) {
+            const uint64_t step = (uint64_t)(p.step0 + (uint32_t)s + 1u);
+            const smcmc_u32x4 sblk = smcmc_draw_block(p.seed, gid, step, sd >> 2, SMCMC_STREAM_STEP);
+            double val;
+            if (p.scan_uniform) {
+                val = p.scan_a + (p.scan_b - p.scan_a) * smcmc_u01(smcmc_select_word(sblk, sd & 3u));
+            } else {
+                double nc, ns;
+                smcmc_normal_pair(smcmc_select_word(sblk, sd & 2u), smcmc_select_word(sblk, (sd & 2u) + 1u), &nc, &ns);
+                val = p.scan_a + p.scan_b * ((sd & 1u) ? ns : nc);
+            }
+#pragma unroll
+            for (int d = 0; d < DP; ++d) xp[d] = ((uint32_t)d == sd) ? val : xcol[d * kXStride];
+            const smcmc_u32x4 ablk = smcmc_draw_block(p.seed, gid, step, aw >> 2, SMCMC_STREAM_STEP);
+            finish_step(s, smcmc_select_word(ablk, aw & 3u));
+        }
+        s0 = p.nsteps;
+    }
+
     for (int s = s0; s < p.nsteps; ++s) {
         const uint64_t step = (uint64_t)(p.step0 + (uint32_t)s + 1u);   // ++fTotalSteps, :376
 
@@ -510,6 +541,22 @@ __global__ void __launch_bounds__(kWave, 2) step_kernel(const StepParams p) {
             smcmc_u32x4 blk = smcmc_draw_block(p.seed, gid, step, aw >> 2, SMCMC_STREAM_STEP);
             uword = smcmc_select_word(blk, aw & 3u);
         }
+        if (SPECIAL && p.uniform_mask != 0) {
+            // uniform dimensions (TSimpleMCMC.H:711-716): word d of the step makes the draw; their
+            // rows and columns of the device copy of U are zero, so nothing else touched them
+            const cptr_f64 ub = as_const(p.uniform);
+            uint64_t m = p.uniform_mask;
+#pragma nounroll
+            while (m != 0) {
+                const uint32_t ud = (uint32_t)__builtin_ctzll(m);
+                m &= m - 1;
+                const smcmc_u32x4 ublk = smcmc_draw_block(p.seed, gid, step, ud >> 2, SMCMC_STREAM_STEP);
+                const double lo = ub[ud], hi = ub[DP + ud];
+                const double val = lo + (hi - lo) * smcmc_u01(smcmc_select_word(ublk, ud & 3u));
+#pragma unroll
+                for (int d = 0; d < DP; ++d) xp[d] = ((uint32_t)d == ud) ? val : xp[d];
+            }
+        }
         finish_step(s, uword);
     }
 
@@ -597,17 +644,17 @@ __global__ void reduce_final_kernel(const double* __restrict__ chunk_sums, int n
 
 // Host-callable launchers, one translation unit per (DP, likelihood) (smcmc_inst.hip).
 template <int DP, int LIKE> hipError_t launch_step_like(const StepParams& p, bool exact, bool fullu, bool moments,
-                                                        hipStream_t stream);
+                                                        bool special, hipStream_t stream);
 template <int DP> hipError_t launch_reduce(double* gacc, int ngroups, int D, double* chunk_sums, double* moments,
                                            hipStream_t stream);
 
 template <int DP>
-inline hipError_t launch_step(const StepParams& p, int like, bool exact, bool fullu, bool moments,
+inline hipError_t launch_step(const StepParams& p, int like, bool exact, bool fullu, bool moments, bool special,
                               hipStream_t stream) {
     switch (like) {
-        case SMCMC_LIKE_ISO_GAUSS: return launch_step_like<DP, SMCMC_LIKE_ISO_GAUSS>(p, exact, fullu, moments, stream);
-        case SMCMC_LIKE_QUADFORM: return launch_step_like<DP, SMCMC_LIKE_QUADFORM>(p, exact, fullu, moments, stream);
-        case SMCMC_LIKE_ROSENBROCK: return launch_step_like<DP, SMCMC_LIKE_ROSENBROCK>(p, exact, fullu, moments, stream);
+        case SMCMC_LIKE_ISO_GAUSS: return launch_step_like<DP, SMCMC_LIKE_ISO_GAUSS>(p, exact, fullu, moments, special, stream);
+        case SMCMC_LIKE_QUADFORM: return launch_step_like<DP, SMCMC_LIKE_QUADFORM>(p, exact, fullu, moments, special, stream);
+        case SMCMC_LIKE_ROSENBROCK: return launch_step_like<DP, SMCMC_LIKE_ROSENBROCK>(p, exact, fullu, moments, special, stream);
         default: return hipErrorInvalidValue;
     }
 }

@@ -91,6 +91,9 @@ class Engine:
     def SetUniform(self, dim, minimum, maximum):
         self._check(self._lib.smcmc_set_uniform(self._h, dim, minimum, maximum))
 
+    def SetScanDimension(self, dim):
+        self._check(self._lib.smcmc_set_scan_dimension(self._h, dim))
+
     def SetCorrelation(self, dim1, dim2, correlation):
         self._check(self._lib.smcmc_set_correlation(self._h, dim1, dim2, correlation))
 

@@ -327,3 +327,78 @@ def test_pooled_large_dim_matches_oracle(gpu, oracle, dim, nchains, stride, wind
         assert np.array_equal(e.decomposition, o.decomposition)
     e.Step(2); o.step(2)
     _assert_same_state(e, o, "after the last sync")
+
+
+# ---------------------------------------------------------------- uniform dimensions and scan
+@pytest.mark.parametrize("mode", ["frozen", "pooled"])
+@pytest.mark.parametrize("kind,dim,nchains", [(0, 5, 70), (2, 6, 64), (0, 50, 128)])
+def test_uniform_dimensions_match_oracle(gpu, oracle, mode, kind, dim, nchains):
+    """SetUniform (TSimpleMCMC.H:833-848, 711-716, 721): the uniform dimensions are redrawn
+    from their range every step and take no part in the Gaussian move."""
+    m = gpu.MODE_FROZEN if mode == "frozen" else gpu.MODE_POOLED
+
+    def setup(e, o):
+        for d, lo, hi in ((1, -0.5, 0.75), (dim - 1, 0.25, 1.5)):
+            e.SetUniform(d, lo, hi)
+            o.set_uniform(d, lo, hi)
+        e.SetGaussian(0, 0.5)
+        o.set_gaussian(0, 0.5)
+
+    rng = np.random.default_rng(3)
+    e, o = _pair(gpu, oracle, dim, nchains, kind, m, True, setup=setup)
+    x0 = _start(kind, dim, nchains, rng)
+    assert e.Start(x0) and o.start(x0)
+    for w in range(3):
+        e.Step(25); o.step(25)
+        _assert_same_state(e, o, f"{mode} window {w}")
+        if mode == "pooled":
+            e.sync(); o.sync()
+            assert np.array_equal(e.decomposition, o.decomposition)
+    x = e.GetAccepted()[:, e.lane("naccept") > 0]          # chains that have moved off their start
+    assert x.shape[1] > nchains // 2
+    assert np.all((x[1] >= -0.5) & (x[1] <= 0.75)) and np.all((x[dim - 1] >= 0.25) & (x[dim - 1] <= 1.5))
+    assert len(np.unique(x[1])) > x.shape[1] // 2
+
+
+def test_uniform_needs_reference_order(gpu):
+    e = gpu.Engine(5, 10, exact=False)
+    e.SetUniform(2, -1.0, 1.0)
+    e.Start(np.zeros(5))
+    with pytest.raises(gpu.SmcmcError) as err:
+        e.Step(1)
+    assert err.value.status == 5   # SMCMC_ERR_UNSUPPORTED
+
+
+@pytest.mark.parametrize("uniform", [False, True])
+def test_scan_dimension_matches_reference_chain(gpu, oracle, uniform):
+    """SetScanDimension (TSimpleMCMC.H:685-704, 820-830): only that dimension is redrawn (about
+    the estimated centre, or uniformly) and the proposal state stays as it was."""
+    dim, nchains, sd, steps = 6, 70, 3, 40
+    e = gpu.Engine(dim, nchains, mode=gpu.MODE_FROZEN)
+    if uniform:
+        e.SetUniform(sd, -2.0, 1.0)
+    else:
+        e.SetGaussian(sd, 0.7)
+    start = np.linspace(-0.3, 0.4, dim)
+    assert e.Start(start)
+    trials = e.lane("trials").copy()
+    e.SetScanDimension(sd)
+    e.Step(steps)
+    x, logl = e.GetAccepted(), e.GetAcceptedLogLikelihood()
+    assert np.array_equal(e.lane("trials"), trials)
+    other = [d for d in range(dim) if d != sd]
+    assert np.array_equal(x[other], np.repeat(start[other, None], nchains, axis=1))
+    for ch in (0, 1, 33, 69):
+        c = oracle.Chain(dim, chain_id=ch)
+        if uniform:
+            c.set_uniform(sd, -2.0, 1.0)
+        else:
+            c.set_gaussian(sd, 0.7)
+        assert c.start(start)
+        c.set_scan_dimension(sd)
+        c.run_quiet(steps)
+        assert np.array_equal(c.accepted, x[:, ch])
+        assert c.scalars["accepted_logl"] == logl[ch]
+    e.SetScanDimension(-1)
+    e.Step(5)
+    assert np.array_equal(e.lane("trials"), trials + 5)

@@ -1,5 +1,5 @@
 // SimpleMCMC_amd.C -- the reference's working example (SimpleMCMC.C:45-301) on the
-// MI355X engine: same command line (cycles, steps, output, [chains]), same
+// MI355X engine: same command line (cycles, steps, output, [dim, chains, restore]), same
 // schedule (one unsaved burn-in pass, ResetProposal, four burn-in passes with
 // UpdateProposal, then cycles x steps with UpdateProposal per cycle, a final
 // forced SaveStep), same tree schema.  Differences: the likelihood dimension is
@@ -15,6 +15,9 @@
 #include <string>
 
 #include "TSimpleMCMC_amd.H"
+#ifdef SMCMC_HAVE_ROOT
+#include <TFile.h>
+#endif
 
 namespace {
 
@@ -32,7 +35,7 @@ void RunSteps(MCMC& mcmc, int steps, int window, bool saveLast) {
 
 }  // namespace
 
-int SimpleMCMC(int cycles, int steps, const char* outputName, int dim, int chains) {
+int SimpleMCMC(int cycles, int steps, const char* outputName, int dim, int chains, const char* restoreName) {
     std::cout << "Simple MCMC (MI355X engine) D=" << dim << " chains=" << chains << std::endl;
     sMCMC::TreeType tree("SimpleMCMC", "Tree of accepted points");
     sMCMC::TSimpleMCMC<sMCMC::TDummyLogLikelihood> mcmc(&tree, true);
@@ -46,6 +49,18 @@ int SimpleMCMC(int cycles, int steps, const char* outputName, int dim, int chain
     if (!mcmc.Start(p, false)) {
         std::cout << "bad starting point" << std::endl;
         return 1;
+    }
+    if (restoreName) {                              // SimpleMCMC.C:50-55, 153-157
+        std::cout << "Restore from " << restoreName << std::endl;
+#ifdef SMCMC_HAVE_ROOT
+        TFile restoreFile(restoreName, "old");
+        mcmc.Restore((TTree*)restoreFile.Get("SimpleMCMC"));
+#else
+        sMCMC::TColumnTree restoreTree = sMCMC::TColumnTree::ReadCsv(restoreName);
+        mcmc.Restore(&restoreTree);
+#endif
+        std::cout << "State Restored: trials " << mcmc.GetProposeStep().GetTrials() << " sigma "
+                  << mcmc.GetProposeStep().GetSigma() << std::endl;
     }
     const int window = 256;
 
@@ -100,8 +115,9 @@ int main(int argc, char** argv) {
     if (argc > 3) outputName = argv[3];
     if (argc > 4) { std::istringstream in(argv[4]); in >> dim; }
     if (argc > 5) { std::istringstream in(argv[5]); in >> chains; }
+    const char* restoreName = (argc > 6) ? argv[6] : NULL;
     try {
-        return SimpleMCMC(cycles, steps, outputName.c_str(), dim, chains);
+        return SimpleMCMC(cycles, steps, outputName.c_str(), dim, chains, restoreName);
     } catch (const std::exception& e) {
         std::cerr << "SimpleMCMC_amd: " << e.what() << std::endl;
         return 2;

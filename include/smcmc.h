@@ -133,6 +133,29 @@ int smcmc_reset_correlations(smcmc_engine* h);                                  
 int smcmc_set_param(smcmc_engine* h, int which, double value);
 int smcmc_get_param(smcmc_engine* h, int which, double* value);
 
+/* One entry of the reference's output tree (branches of TSimpleMCMC.H:208-215 and 1616-1626),
+ * as SaveStep(true) writes it and Restore / RestoreState read it back (:282-352, :1501-1612). */
+typedef struct smcmc_saved_state {
+    double log_likelihood;              /* LogLikelihood */
+    int32_t total_steps;                /* TotalSteps */
+    double step_rms;                    /* StepRMS */
+    int32_t trials;                     /* AdaptiveTrials */
+    int32_t successes;                  /* AdaptiveSuccesses */
+    int32_t next_update;                /* AdaptiveNextUpdate */
+    double acceptance;                  /* AdaptiveAcceptance */
+    double acceptance_trials;           /* AdaptiveAcceptanceTrials */
+    double sigma;                       /* AdaptiveSigma */
+    const double* central_point;        /* AdaptiveCentralPoint [dim] */
+    double central_point_trials;        /* AdaptiveCentralPointTrials */
+    const double* covariance;           /* AdaptiveCovariance: lower triangle, row major, dim (dim + 1) / 2 */
+    double covariance_trials;           /* AdaptiveCovarianceTrials */
+} smcmc_saved_state;
+/* Restore(tree) (TSimpleMCMC.H:282-352, randomize = false) on a started engine: every chain
+ * continues from `accepted` ([dim] broadcast or [dim][nchains]) with the saved state; the
+ * likelihood is recomputed on the device and replaces the saved one when they differ by more
+ * than 1E-4; the proposal is updated once (RestoreState, :1612). */
+int smcmc_restore(smcmc_engine* h, const double* accepted, int broadcast, const smcmc_saved_state* state);
+
 /* ---- the chain ---------------------------------------------------------- */
 /* Start (TSimpleMCMC.H:246-276) + InitializeState (:1679-1714).  x0 is [dim] when
  * broadcast != 0, else [dim][nchains].  SMCMC_ERR_BAD_START when any chain's start

@@ -66,6 +66,9 @@ def _declare(L):
         f.argtypes = [C.c_void_p] + args
     L.oracle_chain_start_api.restype = C.c_int
     L.oracle_chain_start_api.argtypes = [C.c_void_p, _dp]
+    L.oracle_chain_restore_api.restype = None
+    L.oracle_chain_restore_api.argtypes = [C.c_void_p, _dp, C.c_double, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int,
+                                           C.c_double, C.c_double, C.c_double, _dp, C.c_double, _dp, C.c_double]
     L.oracle_chain_step_api.restype = C.c_int
     L.oracle_chain_step_api.argtypes = [C.c_void_p, C.c_int, C.c_int]
     L.oracle_chain_run.restype = None
@@ -192,6 +195,26 @@ class Chain:
 
     def step(self, save=False, metropolis=0):
         return bool(lib().oracle_chain_step_api(self._h, int(save), metropolis))
+
+    def saved_state(self):
+        """What SaveStep(true) writes for this chain (TSimpleMCMC.H:208-215, 1616-1673)."""
+        sc = self.scalars
+        cov = self.covariance
+        return dict(accepted=self.accepted, log_likelihood=sc["accepted_logl"], total_steps=int(sc["total_steps"]),
+                    step_rms=sc["step_rms"], trials=int(sc["trials"]), successes=int(sc["successes"]),
+                    next_update=int(sc["next_update"]), acceptance=sc["acceptance"],
+                    acceptance_trials=sc["acceptance_trials"], sigma=sc["sigma"], central_point=self.center,
+                    central_point_trials=sc["central_trials"],
+                    covariance=np.array([cov[i, j] for i in range(self.dim) for j in range(i + 1)]),
+                    covariance_trials=sc["cov_trials"])
+
+    def restore(self, st):
+        """Restore(tree) + RestoreState (TSimpleMCMC.H:282-352, 1501-1612) from a saved_state() dict."""
+        lib().oracle_chain_restore_api(self._h, _p(_f64(st["accepted"])), st["log_likelihood"], st["total_steps"],
+                                       st["step_rms"], st["trials"], st["successes"], st["next_update"],
+                                       st["acceptance"], st["acceptance_trials"], st["sigma"],
+                                       _p(_f64(st["central_point"])), st["central_point_trials"],
+                                       _p(_f64(st["covariance"])), st["covariance_trials"])
 
     def run(self, nsteps, metropolis=0):
         out = dict(accepted=np.zeros(nsteps, np.uint8), logl_proposed=np.zeros(nsteps),

@@ -540,6 +540,58 @@ static int oracle_chain_start(oracle_chain* c, const double* start) {
     return 1;
 }
 
+/* RestoreState TSimpleMCMC.H:1501-1612 with the saved fields of one tree entry
+ * (the branches of :1616-1626); cov_packed is the lower triangle, row major
+ * (:1585-1598). */
+static void oracle_proposal_restore(oracle_proposal* p, const double* current, double value,
+                                    int trials, int successes, int next_update, double acceptance,
+                                    double acceptance_trials, double sigma, const double* central,
+                                    double central_trials, const double* cov_packed, double cov_trials) {
+    const int n = p->dim;
+    p->state_initialized = 1;                                       /* :1503 */
+    p->last_value = value;                                          /* :1514 */
+    memcpy(p->last_point, current, sizeof(double) * (size_t)n);
+    p->trials = trials;                                             /* :1563-1570 */
+    p->successes = successes;
+    p->next_update = next_update;
+    p->acceptance = acceptance;
+    p->acceptance_trials = acceptance_trials;
+    p->sigma = sigma;
+    memcpy(p->central, central, sizeof(double) * (size_t)n);
+    p->central_trials = central_trials;
+    const double* cov = cov_packed;                                 /* :1574-1586 */
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < i + 1; ++j) {
+            p->cov[i * n + j] = p->cov[j * n + i] = *cov;
+            ++cov;
+        }
+    p->sigma_trace = oracle_proposal_trace(p);                      /* :1587 */
+    p->cov_trials = cov_trials;                                     /* :1588 */
+    oracle_proposal_update(p, 0);                                   /* :1612 */
+}
+
+/* Restore TSimpleMCMC.H:282-352 from the last entry of a tree (randomize = false):
+ * the saved likelihood is kept unless the recomputed one differs by more than 1E-4. */
+static void oracle_chain_restore(oracle_chain* c, const double* accepted, double saved_logl,
+                                 int total_steps, double step_rms,
+                                 int trials, int successes, int next_update, double acceptance,
+                                 double acceptance_trials, double sigma, const double* central,
+                                 double central_trials, const double* cov_packed, double cov_trials) {
+    size_t n = (size_t)c->dim;
+    c->total_steps = total_steps;                                   /* :320-323 */
+    c->accepted_logl = saved_logl;
+    c->step_rms = step_rms;
+    memcpy(c->accepted, accepted, sizeof(double) * n);
+    memcpy(c->proposed, accepted, sizeof(double) * n);
+    memcpy(c->trial_step, accepted, sizeof(double) * n);
+    c->proposed_logl = oracle_chain_like(c, c->proposed);           /* :335 */
+    double delta = c->proposed_logl - c->accepted_logl;
+    if (fabs(delta) > 1E-4) c->accepted_logl = c->proposed_logl;    /* :337-345 */
+    oracle_proposal_restore(&c->prop, c->accepted, c->accepted_logl, trials, successes, next_update,
+                            acceptance, acceptance_trials, sigma, central, central_trials,
+                            cov_packed, cov_trials);                /* :351 */
+}
+
 /* Step TSimpleMCMC.H:370-496.  Returns 1 when a new point was accepted. */
 static int oracle_chain_step(oracle_chain* c, int save, int metropolis) {
     const int n = c->dim;

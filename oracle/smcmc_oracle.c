@@ -77,6 +77,13 @@ void oracle_chain_update_proposal(oracle_chain* c) { oracle_proposal_update(&c->
 void oracle_chain_reset_proposal(oracle_chain* c) { oracle_proposal_reset(&c->prop); }
 
 int oracle_chain_start_api(oracle_chain* c, const double* start) { return oracle_chain_start(c, start); }
+void oracle_chain_restore_api(oracle_chain* c, const double* accepted, double saved_logl, int total_steps,
+                              double step_rms, int trials, int successes, int next_update, double acceptance,
+                              double acceptance_trials, double sigma, const double* central,
+                              double central_trials, const double* cov_packed, double cov_trials) {
+    oracle_chain_restore(c, accepted, saved_logl, total_steps, step_rms, trials, successes, next_update,
+                         acceptance, acceptance_trials, sigma, central, central_trials, cov_packed, cov_trials);
+}
 int oracle_chain_step_api(oracle_chain* c, int save, int metropolis) { return oracle_chain_step(c, save, metropolis); }
 
 /* Run n steps, recording per-step observables (any out pointer may be NULL).

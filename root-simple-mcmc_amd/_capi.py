@@ -30,6 +30,15 @@ _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)
 _H = C.c_void_p
 
+class SavedState(C.Structure):
+    """smcmc_saved_state: one entry of the reference's output tree."""
+    _fields_ = [("log_likelihood", C.c_double), ("total_steps", C.c_int32), ("step_rms", C.c_double),
+                ("trials", C.c_int32), ("successes", C.c_int32), ("next_update", C.c_int32),
+                ("acceptance", C.c_double), ("acceptance_trials", C.c_double), ("sigma", C.c_double),
+                ("central_point", _dp), ("central_point_trials", C.c_double),
+                ("covariance", _dp), ("covariance_trials", C.c_double)]
+
+
 # every symbol include/smcmc.h declares: name -> (restype, argtypes)
 SIGNATURES = {
     "smcmc_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint32, C.c_int, C.POINTER(_H)]),
@@ -50,6 +59,7 @@ SIGNATURES = {
     "smcmc_set_param": (C.c_int, [_H, C.c_int, C.c_double]),
     "smcmc_get_param": (C.c_int, [_H, C.c_int, _dp]),
     "smcmc_start": (C.c_int, [_H, _dp, C.c_int]),
+    "smcmc_restore": (C.c_int, [_H, _dp, C.c_int, C.POINTER(SavedState)]),
     "smcmc_step": (C.c_int, [_H, C.c_int, C.c_int]),
     "smcmc_step_save": (C.c_int, [_H, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "smcmc_force_step": (C.c_int, [_H, _dp, C.c_int]),

@@ -567,14 +567,17 @@ int smcmc_get_param(smcmc_engine* h, int which, double* out) {
     return SMCMC_OK;
 }
 
-int smcmc_start(smcmc_engine* h, const double* x0, int broadcast) {
-    if (!h || !x0) return SMCMC_ERR_INVALID;
+// Puts every chain at x0 and evaluates the likelihood there on the device (the
+// GetLogLikelihoodValue call of Start, TSimpleMCMC.H:258, and of Restore, :335).  All per-chain
+// columns are zero afterwards except the likelihood; x and logl come back for the caller.
+static int place_chains(smcmc_engine* h, const double* x0, int broadcast, std::vector<double>& x,
+                        std::vector<double>& logl) {
     HIP_TRY(h, hipSetDevice(h->device));
     const int D = h->dim, N = h->nchains;
     const size_t NP = (size_t)h->npad;
     int st = upload_like(h);
     if (st) return st;
-    std::vector<double> x(NP * h->dp, 0.0);
+    x.assign(NP * h->dp, 0.0);
     for (int d = 0; d < D; ++d)
         for (int c = 0; c < N; ++c) x[(size_t)d * NP + c] = broadcast ? x0[d] : x0[(size_t)d * N + c];
     HIP_TRY(h, hipMemcpyAsync(h->d_x, x.data(), x.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -606,10 +609,20 @@ int smcmc_start(smcmc_engine* h, const double* x0, int broadcast) {
         hipError_t e = dispatch_step(h->dp, p, h->likelihood, h->exact, false, false, h->stream);
         if (e != hipSuccess) return fail(h, SMCMC_ERR_HIP, std::string("start kernel launch: ") + hipGetErrorString(e));
     }
-    std::vector<double> logl(NP, 0.0);
+    logl.assign(NP, 0.0);
     HIP_TRY(h, hipMemcpyAsync(logl.data(), h->d_lane_f64 + (size_t)SMCMC_LANE_LOGL * NP, NP * sizeof(double),
                               hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SMCMC_OK;
+}
+
+int smcmc_start(smcmc_engine* h, const double* x0, int broadcast) {
+    if (!h || !x0) return SMCMC_ERR_INVALID;
+    const int D = h->dim, N = h->nchains;
+    const size_t NP = (size_t)h->npad;
+    std::vector<double> x, logl;
+    int st = place_chains(h, x0, broadcast, x, logl);
+    if (st) return st;
     for (int c = 0; c < N; ++c)
         if (!std::isfinite(logl[c]) || logl[c] < -0.999999E+10)                      // :265-268
             return fail(h, SMCMC_ERR_BAD_START, "start likelihood is not finite or < -0.999999E+10");
@@ -647,6 +660,68 @@ int smcmc_start(smcmc_engine* h, const double* x0, int broadcast) {
     h->has_forced = false;
     h->started = true;
     return SMCMC_OK;
+}
+
+// Restore (TSimpleMCMC.H:282-352, randomize = false) followed by
+// TProposeAdaptiveStep::RestoreState (:1501-1612): every chain resumes from `accepted` with the
+// saved scalar state of the tree entry; the shared proposal takes the saved centre and covariance
+// and is updated once (:1612).
+int smcmc_restore(smcmc_engine* h, const double* accepted, int broadcast, const smcmc_saved_state* s) {
+    if (!h || !accepted || !s || !s->central_point || !s->covariance) return SMCMC_ERR_INVALID;
+    if (!h->started)
+        return fail(h, SMCMC_ERR_INVALID, "Restore needs a started chain (Start first, SimpleMCMC.C:151-154)");
+    const int D = h->dim, N = h->nchains;
+    const size_t NP = (size_t)h->npad;
+    std::vector<double> x, logl;
+    int st = place_chains(h, accepted, broadcast, x, logl);
+    if (st) return st;
+    // the saved likelihood stands unless the recomputed one differs by more than 1E-4 (:336-345)
+    for (int c = 0; c < N; ++c)
+        if (!(std::fabs(logl[c] - s->log_likelihood) > 1E-4)) logl[c] = s->log_likelihood;
+
+    SharedProposal& P = *h->prop;
+    P.initialized = true;                                                            // :1503
+    for (int d = 0; d < D; ++d) P.lastPoint[d] = x[(size_t)d * NP];                  // chain 0, :1515
+    P.successes = s->successes;                                                      // :1563-1570
+    P.nextUpdate = s->next_update;
+    P.acceptance = s->acceptance;
+    P.acceptanceTrials = s->acceptance_trials;
+    P.sigma = s->sigma;
+    for (int d = 0; d < D; ++d) P.centre[d] = s->central_point[d];
+    P.centreTrials = s->central_point_trials;
+    const double* cov = s->covariance;                                               // :1574-1586
+    for (int i = 0; i < D; ++i)
+        for (int j = 0; j < i + 1; ++j) P.C(i, j) = P.C(j, i) = *cov++;
+    P.sigmaTrace = P.trace();                                                        // :1587
+    P.covTrials = s->covariance_trials;
+    st = status_of(h, P.update(false));                                              // :1612
+    if (st) return st;
+
+    std::vector<double> lf(NP * SMCMC_LANE_F64_COUNT_, 0.0);
+    std::vector<int32_t> li(NP * SMCMC_LANE_I32_COUNT_, 0);
+    for (int c = 0; c < N; ++c) {
+        lf[(size_t)SMCMC_LANE_LOGL * NP + c] = logl[c];
+        lf[(size_t)SMCMC_LANE_SIGMA * NP + c] = P.sigma;
+        lf[(size_t)SMCMC_LANE_ACCEPTANCE * NP + c] = P.acceptance;
+        lf[(size_t)SMCMC_LANE_ACCEPTANCE_TRIALS * NP + c] = P.acceptanceTrials;
+        lf[(size_t)SMCMC_LANE_RIGIDITY * NP + c] = P.rigidity;
+        lf[(size_t)SMCMC_LANE_LAST_VALUE * NP + c] = logl[c];
+        lf[(size_t)SMCMC_LANE_LAST_X0 * NP + c] = x[c];
+        lf[(size_t)SMCMC_LANE_STEP_RMS * NP + c] = s->step_rms;
+        lf[(size_t)SMCMC_LANE_LOGL_PROPOSED * NP + c] = logl[c];
+        li[(size_t)SMCMC_LANE_TRIALS * NP + c] = s->trials;
+        li[(size_t)SMCMC_LANE_SUCCESSES * NP + c] = s->successes;
+        li[(size_t)SMCMC_LANE_NEXT_UPDATE * NP + c] = P.nextUpdate;
+    }
+    HIP_TRY(h, hipMemcpyAsync(h->d_lane_f64, lf.data(), lf.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_lane_i32, li.data(), li.size() * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->d_gacc, 0, sizeof(double) * gacc_doubles(h), h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->total_steps = (uint32_t)s->total_steps;
+    h->pending_sigma_scale = 1.0;
+    h->pending_deweight = 0;
+    h->has_forced = false;
+    return upload_shared(h);
 }
 
 int smcmc_step(smcmc_engine* h, int nsteps, int metropolis) {
@@ -745,6 +820,19 @@ int smcmc_update_proposal(smcmc_engine* h) {
     if (st) return st;
     h->pending_sigma_scale *= scale;
     h->pending_deweight = 1;
+    if (h->mode == SMCMC_MODE_FROZEN) {
+        // every chain reschedules its own next update from its own successes (:1050-1052)
+        const size_t NP = (size_t)h->npad;
+        std::vector<int32_t> succ(NP), next(NP);
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        HIP_TRY(h, hipMemcpy(succ.data(), h->d_lane_i32 + (size_t)SMCMC_LANE_SUCCESSES * NP, NP * sizeof(int32_t),
+                             hipMemcpyDeviceToHost));
+        const double maxUp = (double)h->dim * (double)h->dim;
+        for (size_t c = 0; c < NP; ++c)
+            next[c] = (int32_t)(P.acceptanceWindow + maxUp - maxUp / (0.5 * succ[c] + 1.0));
+        HIP_TRY(h, hipMemcpy(h->d_lane_i32 + (size_t)SMCMC_LANE_NEXT_UPDATE * NP, next.data(), NP * sizeof(int32_t),
+                             hipMemcpyHostToDevice));
+    }
     return upload_shared(h);
 }
 

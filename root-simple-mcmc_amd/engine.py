@@ -157,6 +157,38 @@ class Engine:
         self._check(st)
         return True
 
+    def saved_state(self, chain=0):
+        """What SaveStep(true) writes for one chain (branches of TSimpleMCMC.H:208-215, 1616-1626):
+        its point and scalar state plus the shared centre and covariance."""
+        cov = self.covariance
+        return dict(accepted=self.GetAccepted()[:, chain].copy(),
+                    log_likelihood=float(self.GetAcceptedLogLikelihood()[chain]),
+                    total_steps=int(self.get_param("TOTAL_STEPS")), step_rms=float(self.lane("step_rms")[chain]),
+                    trials=int(self.lane("trials")[chain]), successes=int(self.lane("successes")[chain]),
+                    next_update=int(self.lane("next_update")[chain]),
+                    acceptance=float(self.lane("acceptance")[chain]),
+                    acceptance_trials=float(self.lane("acceptance_trials")[chain]),
+                    sigma=float(self.lane("sigma")[chain]), central_point=self.GetEstimatedCenter(),
+                    central_point_trials=self.get_param("CENTER_TRIALS"),
+                    covariance=np.array([cov[i, j] for i in range(self.dim) for j in range(i + 1)]),
+                    covariance_trials=self.get_param("COVARIANCE_TRIALS"))
+
+    def Restore(self, state, accepted=None):
+        """Restore(tree) (TSimpleMCMC.H:282-352) from a saved_state() dict; `accepted` ([dim] or
+        [dim][nchains]) overrides state["accepted"] as the point(s) to continue from."""
+        x = _f64(state["accepted"] if accepted is None else accepted)
+        broadcast = int(x.ndim == 1)
+        if not broadcast and x.shape != (self.dim, self.nchains):
+            raise ValueError("accepted must be [dim] or [dim][nchains]")
+        centre, cov = _f64(state["central_point"]), _f64(state["covariance"])
+        if centre.size != self.dim or cov.size != self.dim * (self.dim + 1) // 2:
+            raise ValueError("saved centre / packed covariance have the wrong size")
+        st = _capi.SavedState(state["log_likelihood"], state["total_steps"], state["step_rms"], state["trials"],
+                              state["successes"], state["next_update"], state["acceptance"],
+                              state["acceptance_trials"], state["sigma"], _ptr(centre),
+                              state["central_point_trials"], _ptr(cov), state["covariance_trials"])
+        self._check(self._lib.smcmc_restore(self._h, _ptr(x), broadcast, C.byref(st)))
+
     def Step(self, nsteps=1, metropolis=0):
         """nsteps x Step(save=false, metropolis) of every chain, one launch."""
         self._check(self._lib.smcmc_step(self._h, int(nsteps), int(metropolis)))

@@ -53,3 +53,27 @@ def test_example_runs_the_reference_schedule(gpu, tmp_path):
     assert 0.15 < np.mean(acc) < 0.35
     trace = float(last[col["AdaptiveCovarianceTrace"]])
     assert abs(trace / 5.0 - 1.0) < 0.2
+
+
+@pytest.mark.gpu
+def test_example_continues_a_chain_from_its_output(gpu, tmp_path):
+    """`mcmc.exe cycles steps out in` (README.md:132-137, SimpleMCMC.C:50-55, 153-157): the second
+    run restores the last entry of the first run's tree and carries on from there."""
+    exe = _build(tmp_path)
+    first, second = tmp_path / "first.csv", tmp_path / "second.csv"
+    r = subprocess.run([exe, "2", "1000", str(first), "5", "128"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    r = subprocess.run([exe, "1", "500", str(second), "5", "128", str(first)], capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "State Restored" in r.stdout
+
+    def last_row(path):
+        lines = open(path).read().splitlines()
+        header = lines[0].split(",")
+        return dict(zip(header, lines[-1].split(",")))
+
+    a, b = last_row(first), last_row(second)
+    assert int(a["TotalSteps"]) == (1 + 4 + 2) * 1000
+    assert int(b["TotalSteps"]) == int(a["TotalSteps"]) + (1 + 4 + 1) * 500      # the step count carries over
+    assert abs(float(b["AdaptiveCovarianceTrace"]) / 5.0 - 1.0) < 0.25

@@ -402,3 +402,68 @@ def test_scan_dimension_matches_reference_chain(gpu, oracle, uniform):
     e.SetScanDimension(-1)
     e.Step(5)
     assert np.array_equal(e.lane("trials"), trials + 5)
+
+
+# ---------------------------------------------------------------- Restore
+@pytest.mark.parametrize("kind,dim", [(0, 5), (2, 6), (0, 50)])
+def test_restore_continues_like_the_reference_chain(gpu, oracle, kind, dim):
+    """Restore (TSimpleMCMC.H:282-352, 1501-1612): a chain saved by the CPU restatement is picked
+    up by the engine; every lane then equals the reference chain restored from the same entry."""
+    prm = _like_params(oracle, kind, dim)
+    src = oracle.Chain(dim, kind=kind, params=prm, chain_id=2)
+    x0 = np.full(dim, 0.9) if kind == 2 else np.zeros(dim)
+    assert src.start(x0)
+    src.run_quiet(900)
+    st = src.saved_state()
+
+    nchains, steps = 70, 300
+    e = gpu.Engine(dim, nchains, likelihood=kind, likelihood_params=prm, mode=gpu.MODE_FROZEN)
+    assert e.Start(x0)
+    e.Restore(st)
+    assert e.get_param("TOTAL_STEPS") == 900
+    assert np.array_equal(e.GetAccepted(), np.repeat(st["accepted"][:, None], nchains, axis=1))
+    e.Step(steps)
+    x = e.GetAccepted()
+    for ch in (0, 2, 64, 69):
+        c = oracle.Chain(dim, kind=kind, params=prm, chain_id=ch)
+        c.set_covariance_frozen(1)
+        assert c.start(x0)
+        c.restore(st)
+        c.run_quiet(steps)
+        sc = c.scalars
+        assert np.array_equal(c.accepted, x[:, ch])
+        assert sc["accepted_logl"] == e.GetAcceptedLogLikelihood()[ch]
+        for name in ("sigma", "acceptance", "acceptance_trials", "step_rms"):
+            assert sc[name] == e.lane(name)[ch], name
+        for name in ("trials", "successes", "next_update"):
+            assert sc[name] == e.lane(name)[ch], name
+    assert np.array_equal(e.decomposition, c.decomposition)
+
+
+def test_restore_round_trip_of_the_pooled_engine(gpu):
+    """saved_state() -> Restore() carries the ensemble's shared centre / covariance and every
+    chain's point into a fresh engine."""
+    dim, n = 9, 200
+    a = gpu.Engine(dim, n)
+    a.Start(np.zeros(dim))
+    for _ in range(4):
+        a.Step(50); a.sync()
+    st = a.saved_state(chain=5)
+    b = gpu.Engine(dim, n)
+    b.Start(np.zeros(dim))
+    b.Restore(st, accepted=a.GetAccepted())
+    assert np.array_equal(b.GetAccepted(), a.GetAccepted())
+    assert np.array_equal(b.GetAcceptedLogLikelihood(), a.GetAcceptedLogLikelihood())
+    assert np.array_equal(b.covariance, a.covariance) and np.array_equal(b.GetEstimatedCenter(), a.GetEstimatedCenter())
+    assert b.get_param("TOTAL_STEPS") == 200 and np.all(b.lane("trials") == st["trials"])
+    b.Step(20); b.sync()
+    assert np.isfinite(b.GetAcceptedLogLikelihood()).all()
+
+
+def test_restore_needs_start(gpu):
+    e = gpu.Engine(4, 8)
+    st = dict(accepted=np.zeros(4), log_likelihood=0.0, total_steps=10, step_rms=0.1, trials=10, successes=3,
+              next_update=5, acceptance=0.3, acceptance_trials=10.0, sigma=0.5, central_point=np.zeros(4),
+              central_point_trials=10.0, covariance=np.eye(4)[np.tril_indices(4)], covariance_trials=10.0)
+    with pytest.raises(gpu.SmcmcError):
+        e.Restore(st)

@@ -211,3 +211,39 @@ def test_debug_modes(oracle):
     f.step(metropolis=2)
     x = f.accepted
     assert x[0] == 0 and x[1] == 0 and x[3] == 0 and x[2] != 0
+
+
+def test_restore_restatement(oracle):
+    """Restore + RestoreState (TSimpleMCMC.H:282-352, 1501-1612): the saved scalar state comes
+    back, the proposal is updated once, the saved likelihood stands unless it is off by > 1E-4."""
+    dim = 5
+    a = oracle.Chain(dim, chain_id=3)
+    assert a.start(np.zeros(dim))
+    a.run_quiet(700)
+    st = a.saved_state()
+    assert st["total_steps"] == 700 and st["covariance"].size == dim * (dim + 1) // 2
+
+    b = oracle.Chain(dim, chain_id=3)
+    assert b.start(np.full(dim, 0.1))              # SimpleMCMC.C:151-154: Start, then Restore
+    b.restore(st)
+    sb = b.scalars
+    assert np.array_equal(b.accepted, st["accepted"]) and sb["accepted_logl"] == st["log_likelihood"]
+    assert sb["total_steps"] == 700 and sb["step_rms"] == st["step_rms"]
+    assert sb["trials"] == st["trials"] and sb["successes"] == st["successes"]
+    assert sb["sigma"] == st["sigma"]                               # trace unchanged: rescale by sqrt(1)
+    window = dim ** 1.5 + 1000
+    assert sb["next_update"] == int(window + dim * dim - dim * dim / (0.5 * st["successes"] + 1.0))   # :1050-1052
+    assert sb["acceptance_trials"] == min(max(1.0, 0.5 * st["acceptance_trials"]), 0.5 * window)      # :1081-1086
+    assert np.array_equal(b.covariance, a.covariance) and np.array_equal(b.center, a.center)
+    assert sb["sigma_trace"] == np.trace(a.covariance)
+    assert np.allclose(b.decomposition.T @ b.decomposition, b.covariance, rtol=1e-12, atol=1e-14)
+    b.run_quiet(50)
+    assert b.scalars["total_steps"] == 750
+
+    near, far = dict(st), dict(st)
+    near["log_likelihood"] = st["log_likelihood"] + 1e-6
+    far["log_likelihood"] = st["log_likelihood"] + 1e-3
+    c = oracle.Chain(dim, chain_id=3); c.start(np.zeros(dim)); c.restore(near)
+    assert c.scalars["accepted_logl"] == near["log_likelihood"]
+    d = oracle.Chain(dim, chain_id=3); d.start(np.zeros(dim)); d.restore(far)
+    assert d.scalars["accepted_logl"] == st["log_likelihood"]

@@ -236,7 +236,8 @@ int smcmc_hmc_read_lane_i32(smcmc_hmc* h, int field, int32_t* out);
 /* ---- self test (no engine needed) --------------------------------------- */
 /* Runs every function of include/smcmc_detmath.h on the device for n inputs so
  * tests can compare device and host bit for bit.  kind: 0 log, 1 exp,
- * 2 sin(2 pi x), 3 cos(2 pi x), 4 pow_small(x, y), 5 sqrt, 6 x / y. */
+ * 2 sin(2 pi x), 3 cos(2 pi x), 4 pow_small(x, y), 5 sqrt, 6 x / y, 7 / 8 the two normals of
+ * the Box-Muller pair made from the 32-bit words x, y, 9 sqrt_mid. */
 int smcmc_selftest_detmath(int device, int kind, int n, const double* x, const double* y, double* out);
 /* One v_mfma_f64_16x16x4_f64 chain: c[16][16] = sum_k a[16][k] b[k][16] over K
  * (multiple of 4), the accumulation order the pooled moments rely on. */

@@ -99,7 +99,8 @@ SMCMC_HD smcmc_u32x4 smcmc_draw_block(uint64_t seed, uint32_t chain, uint64_t st
 
 /* 32-bit word -> u in (0,1): (w + 0.5) * 2^-32, exact in binary64. */
 SMCMC_HD double smcmc_u01(uint32_t w) {
-    return ((double)w + 0.5) * 2.3283064365386962890625e-10;
+    /* w 2^-32 + 2^-33 = (2w + 1) 2^-33: one exact fused operation */
+    return SMCMC_FMA((double)w, 2.3283064365386962890625e-10, 1.16415321826934814453125e-10);
 }
 
 /* ---- log(x), x > 0 finite normal or subnormal ---------------------------
@@ -232,14 +233,63 @@ SMCMC_HD void smcmc_sincos2pi(double u, double* sn, double* cs) {
     *cs = ((j + 1) & 2) ? -rc : rc;
 }
 
+/* sin/cos(2*pi*u) for u = smcmc_u01(w), bit for bit smcmc_sincos2pi(smcmc_u01(w), ...)
+ * with the quadrant and the reduced argument taken from the bits of w instead of
+ * through floating-point rounding tricks: 4u = (w + 1/2) 2^-30 is never half-way
+ * between integers, so j = rint(4u) = (w + 2^29) >> 30 and g = 4u - j =
+ * (d + 1/2) 2^-30 with d = (int32)(w - (j << 30)); x = g pi/2 is one fused operation. */
+SMCMC_HD void smcmc_sincos2pi_u32(uint32_t w, double* sn, double* cs) {
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
+                 S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
+                 S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
+                 C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
+                 C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    const double pio2_30 = 1.57079632679489655800e+00 * 9.31322574615478515625e-10;   /* pi/2 * 2^-30, exact scaling */
+    const uint32_t j = (w >> 30) + ((w >> 29) & 1u);
+    const int32_t d = (int32_t)(w - (j << 30));
+    double x = SMCMC_FMA((double)d, pio2_30, 0.5 * pio2_30);
+    double z = x * x;
+    double ps = SMCMC_FMA(z, SMCMC_FMA(z, SMCMC_FMA(z, SMCMC_FMA(z, SMCMC_FMA(z, S6, S5), S4), S3), S2), S1);
+    double s = SMCMC_FMA(z * x, ps, x);
+    double pc = SMCMC_FMA(z, SMCMC_FMA(z, SMCMC_FMA(z, SMCMC_FMA(z, SMCMC_FMA(z, C6, C5), C4), C3), C2), C1);
+    double hz = 0.5 * z;
+    double c = (1.0 - hz) + (z * z) * pc;
+    const uint32_t swap = j & 1u;
+    double rs = swap ? c : s;
+    double rc = swap ? s : c;
+    /* sign flips through the sign bit: sin negative for j & 2, cos negative for (j + 1) & 2 */
+    *sn = smcmc_u2d(smcmc_d2u(rs) ^ ((uint64_t)(j & 2u) << 62));
+    *cs = smcmc_u2d(smcmc_d2u(rc) ^ ((uint64_t)((j + 1u) & 2u) << 62));
+}
+
+/* sqrt(x) for x well inside the normal range (here 2.3e-10 <= x <= 45): the correctly rounded
+ * root.  On the device this is the rsq + Newton sequence the compiler emits for sqrt() without the
+ * range scaling and the 0 / inf handling that this argument never needs. */
+SMCMC_HD double smcmc_sqrt_mid(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double y = __builtin_amdgcn_rsq(x);
+    double g = x * y;
+    double h = 0.5 * y;
+    double r = SMCMC_FMA(-h, g, 0.5);
+    g = SMCMC_FMA(g, r, g);
+    h = SMCMC_FMA(h, r, h);
+    double e = SMCMC_FMA(-g, g, x);
+    g = SMCMC_FMA(e, h, g);
+    e = SMCMC_FMA(-g, g, x);
+    return SMCMC_FMA(e, h, g);
+#else
+    return __builtin_sqrt(x);
+#endif
+}
+
 /* ---- Box-Muller pair from two 32-bit words -------------------------------
  * n0 = r cos(theta), n1 = r sin(theta), r = sqrt(-2 log u1), theta = 2 pi u2. */
 SMCMC_HD void smcmc_normal_pair(uint32_t w0, uint32_t w1, double* n0, double* n1) {
     double u1 = smcmc_u01(w0);
-    double u2 = smcmc_u01(w1);
-    double r = __builtin_sqrt(-2.0 * smcmc_log_pos(u1));
+    double r = smcmc_sqrt_mid(-2.0 * smcmc_log_pos(u1));
     double sn, cs;
-    smcmc_sincos2pi(u2, &sn, &cs);
+    smcmc_sincos2pi_u32(w1, &sn, &cs);
     *n0 = r * cs;
     *n1 = r * sn;
 }

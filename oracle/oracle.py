@@ -84,6 +84,9 @@ def _declare(L):
     L.oracle_exp_v.argtypes = [C.c_int, _dp, _dp]
     L.oracle_pow_small_v.argtypes = [C.c_int, _dp, _dp, _dp]
     L.oracle_sincos2pi_v.argtypes = [C.c_int, _dp, _dp, _dp]
+    L.oracle_sincos2pi_u32_v.argtypes = [C.c_int, _dp, _dp, _dp]
+    L.oracle_u01_v.argtypes = [C.c_int, _dp, _dp]
+    L.oracle_normal_pair_v.argtypes = [C.c_int, _dp, _dp, _dp, _dp]
     L.oracle_philox.argtypes = [C.c_uint32] * 6 + [C.POINTER(C.c_uint32)]
     L.oracle_step_draws.argtypes = [C.c_uint64, C.c_uint32, C.c_uint64, C.c_int, _dp, _dp]
     L.oracle_cholesky.restype = C.c_int
@@ -354,6 +357,20 @@ def det_pow_small(x, y):
 def det_sincos2pi(u):
     u = _f64(u); s = np.empty_like(u); c = np.empty_like(u)
     lib().oracle_sincos2pi_v(u.size, _p(u), _p(s), _p(c)); return s, c
+
+
+def det_sincos2pi_u32(w):
+    w = _f64(w); s = np.empty_like(w); c = np.empty_like(w)
+    lib().oracle_sincos2pi_u32_v(w.size, _p(w), _p(s), _p(c)); return s, c
+
+
+def det_u01(w):
+    w = _f64(w); out = np.empty_like(w); lib().oracle_u01_v(w.size, _p(w), _p(out)); return out
+
+
+def det_normal_pair(w0, w1):
+    w0 = _f64(w0); w1 = _f64(w1); a = np.empty_like(w0); b = np.empty_like(w0)
+    lib().oracle_normal_pair_v(w0.size, _p(w0), _p(w1), _p(a), _p(b)); return a, b
 
 
 def philox(ctr, key):

@@ -150,6 +150,14 @@ void oracle_pow_small_v(int n, const double* x, const double* y, double* out) {
 void oracle_sincos2pi_v(int n, const double* u, double* s, double* c) {
     for (int i = 0; i < n; ++i) smcmc_sincos2pi(u[i], &s[i], &c[i]);
 }
+/* words are passed as doubles holding exact 32-bit integers */
+void oracle_sincos2pi_u32_v(int n, const double* w, double* s, double* c) {
+    for (int i = 0; i < n; ++i) smcmc_sincos2pi_u32((uint32_t)w[i], &s[i], &c[i]);
+}
+void oracle_u01_v(int n, const double* w, double* out) { for (int i = 0; i < n; ++i) out[i] = smcmc_u01((uint32_t)w[i]); }
+void oracle_normal_pair_v(int n, const double* w0, const double* w1, double* n0, double* n1) {
+    for (int i = 0; i < n; ++i) smcmc_normal_pair((uint32_t)w0[i], (uint32_t)w1[i], &n0[i], &n1[i]);
+}
 void oracle_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t* out) {
     smcmc_u32x4 r = smcmc_philox4x32_10(c0, c1, c2, c3, k0, k1);
     memcpy(out, r.v, sizeof(r.v));

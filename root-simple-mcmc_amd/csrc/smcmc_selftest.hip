@@ -32,6 +32,9 @@ __global__ void detmath_kernel(int kind, int n, const double* __restrict__ x, co
         case 4: r = smcmc_pow_small(a, b); break;
         case 5: r = __builtin_sqrt(a); break;
         case 6: r = a / b; break;
+        case 7: smcmc_normal_pair((uint32_t)a, (uint32_t)b, &c, &s); r = c; break;   // words held as doubles
+        case 8: smcmc_normal_pair((uint32_t)a, (uint32_t)b, &c, &s); r = s; break;
+        case 9: r = smcmc_sqrt_mid(a); break;
         default: break;
     }
     out[i] = r;
@@ -60,7 +63,7 @@ __global__ void __launch_bounds__(64) mfma_chain_kernel(int K, const double* __r
     } while (0)
 
 extern "C" int smcmc_selftest_detmath(int device, int kind, int n, const double* x, const double* y, double* out) {
-    if (n <= 0 || !x || !out || kind < 0 || kind > 6) return SMCMC_ERR_INVALID;
+    if (n <= 0 || !x || !out || kind < 0 || kind > 9) return SMCMC_ERR_INVALID;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return SMCMC_ERR_NO_DEVICE;
     int rc = SMCMC_OK;

@@ -74,3 +74,24 @@ def test_draw_slots(oracle):
     assert np.array_equal(n50[:5], n1)            # normals depend on (seed, chain, step, dim index) only
     w = oracle.philox([1, 0, 1, 0], [1, 0])       # block 1 of chain 0, step 1, seed 1
     assert u1 == (w[2] + 0.5) * 2.0 ** -32        # D=5: word 6 = block 1, lane 2
+
+
+def test_word_forms_equal_the_double_forms(oracle):
+    """The integer-path argument reduction and the fused u01 are bit for bit the
+    floating-point forms they replace (so the draw streams did not change)."""
+    rng = np.random.default_rng(5)
+    w = np.concatenate([rng.integers(0, 2 ** 32, size=200000, dtype=np.uint64),
+                        np.array([0, 1, 2 ** 29 - 1, 2 ** 29, 2 ** 29 + 1, 2 ** 30 - 1, 2 ** 30, 2 ** 31 - 1, 2 ** 31,
+                                  3 * 2 ** 29, 3 * 2 ** 30 - 1, 3 * 2 ** 30, 7 * 2 ** 29 - 1, 7 * 2 ** 29,
+                                  2 ** 32 - 2, 2 ** 32 - 1], dtype=np.uint64)]).astype(np.float64)
+    u = (w + 0.5) * 2.0 ** -32
+    assert np.array_equal(oracle.det_u01(w), u)
+    s0, c0 = oracle.det_sincos2pi(u)
+    s1, c1 = oracle.det_sincos2pi_u32(w)
+    assert np.array_equal(s0, s1) and np.array_equal(c0, c1)
+    # and the pair itself: r = sqrt(-2 log u1), (cos, sin)(2 pi u2)
+    w0, w1 = w, w[::-1].copy()
+    n0, n1 = oracle.det_normal_pair(w0, w1)
+    r = np.sqrt(-2.0 * oracle.det_log((w0 + 0.5) * 2.0 ** -32))
+    s, c = oracle.det_sincos2pi((w1 + 0.5) * 2.0 ** -32)
+    assert np.array_equal(n0, r * c) and np.array_equal(n1, r * s)

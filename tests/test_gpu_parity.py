@@ -76,6 +76,20 @@ def test_detmath_pow_and_div_bitwise(gpu, oracle):
     assert np.array_equal(gpu.selftest_detmath(6, a, b), a / b)
 
 
+def test_normal_pair_device_equals_host_bitwise(gpu, oracle):
+    """Box-Muller from two 32-bit words, including the device-only rsq + Newton square root."""
+    rng = np.random.default_rng(17)
+    w0 = rng.integers(0, 2 ** 32, size=400000, dtype=np.uint64).astype(np.float64)
+    w1 = rng.integers(0, 2 ** 32, size=400000, dtype=np.uint64).astype(np.float64)
+    w0[:4] = [0, 1, 2 ** 32 - 1, 2 ** 31]
+    w1[:4] = [2 ** 32 - 1, 2 ** 29, 3 * 2 ** 29 - 1, 0]
+    n0, n1 = oracle.det_normal_pair(w0, w1)
+    assert np.array_equal(gpu.selftest_detmath(7, w0, w1), n0)
+    assert np.array_equal(gpu.selftest_detmath(8, w0, w1), n1)
+    x = np.concatenate([rng.uniform(2e-10, 45.0, 300000), 10.0 ** rng.uniform(-9.6, 1.6, 300000)])
+    assert np.array_equal(gpu.selftest_detmath(9, x), np.sqrt(x))
+
+
 def test_mfma_f64_is_an_ascending_k_fma_chain(gpu):
     """v_mfma_f64_16x16x4_f64 chained over K folds k = 0..K-1 in order, one fused
     multiply-add per product -- the order oracle/ensemble_oracle.c defines the

@@ -242,6 +242,8 @@ int smcmc_selftest_detmath(int device, int kind, int n, const double* x, const d
 /* One v_mfma_f64_16x16x4_f64 chain: c[16][16] = sum_k a[16][k] b[k][16] over K
  * (multiple of 4), the accumulation order the pooled moments rely on. */
 int smcmc_selftest_mfma(int device, int K, const double* a, const double* b, double* c);
+/* The same for v_mfma_f64_4x4x4_4b_f64 as the moment fold uses it: c[4][16] = sum_k a[4][k] b[k][16]. */
+int smcmc_selftest_mfma_strip(int device, int K, const double* a, const double* b, double* c);
 
 #ifdef __cplusplus
 }

@@ -99,6 +99,7 @@ SIGNATURES = {
     "smcmc_hmc_read_lane_i32": (C.c_int, [_H, C.c_int, _ip]),
     "smcmc_selftest_detmath": (C.c_int, [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp]),
     "smcmc_selftest_mfma": (C.c_int, [C.c_int, C.c_int, _dp, _dp, _dp]),
+    "smcmc_selftest_mfma_strip": (C.c_int, [C.c_int, C.c_int, _dp, _dp, _dp]),
 }
 
 _lib = None

@@ -78,6 +78,13 @@ struct Geo {
     static constexpr int NT = T * (T + 1) / 2;     // lower-triangular tiles
     static constexpr int NB = (DP + 3) / 4;        // Philox blocks of 4 normals
     static constexpr int ROWS_MOMENTS = DP + 1;    // LDS rows of x: the dims and the ones row (zero rows are synthesized)
+    // When at most 4 rows spill into the last 16-row tile (D = 50: rows 48, 49 and the ones row), that tile
+    // row is folded with v_mfma_f64_4x4x4_4b_f64 instead (a quarter of the matrix-pipe time): its four
+    // 4x4 blocks are (strip rows) x (columns 16 t + 4 blk ..), which lands exactly where register 0 of
+    // tile (T-1, t) of the 16x16 scheme would, so the stored layout does not change.
+    static constexpr bool STRIP = ((DP + 1) % 16 != 0) && ((DP + 1) % 16 <= 4);
+    static constexpr int T16 = STRIP ? T - 1 : T;  // tile rows folded with 16x16x4
+    static constexpr int NT16 = T16 * (T16 + 1) / 2;
 };
 
 // LDS image of the decomposition: row i keeps columns j0(i)..DP-1 (j0 = i rounded
@@ -299,15 +306,27 @@ __global__ void __launch_bounds__(kWave, 2) step_kernel(const StepParams p) {
         }
     }
 
-    f64x4 acc[MOMENTS ? NT : 1];
+    constexpr bool STRIP = MOMENTS && Geo<DP>::STRIP;
+    constexpr int NT16 = Geo<DP>::NT16;
+    f64x4 acc[MOMENTS ? NT16 : 1];
+    double accs[STRIP ? T : 1];    // strip accumulators: (row 16 T16 + (lane >> 4), column 16 t + (lane & 15))
     double c0r[MOMENTS ? T : 1];   // c0 of the tile rows this lane feeds to the matrix pipe
     int xrow[MOMENTS ? T : 1];     // LDS row (clamped to the ones row) of those tile rows
+    double c0s = 0.0;              // the same for the strip rows 16 T16 + (lane & 3)
+    int xsrow = 0;
     if constexpr (MOMENTS) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+        for (int t = 0; t < NT16; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 acc[t][r] = p.gacc[(((size_t)group * NT + t) * 4 + r) * kWave + lane];
+        if constexpr (STRIP) {
+#pragma unroll
+            for (int t = 0; t < T; ++t) accs[t] = p.gacc[(((size_t)group * NT + NT16 + t) * 4) * kWave + lane];
+            const int r = 16 * Geo<DP>::T16 + (lane & 3);
+            c0s = (r < DP) ? p.c0[r] : 0.0;
+            xsrow = ((r <= DP) ? r : DP) * kXStride + (lane >> 4);
+        }
         // row DP carries the constant 1 (sum y and the point count come out of the
         // same contraction); tile rows above it are zero and are not stored
         xcol[DP * kXStride] = active ? 1.0 : 0.0;
@@ -461,6 +480,7 @@ __global__ void __launch_bounds__(kWave, 2) step_kernel(const StepParams p) {
         lds_cptr_f64 up = (lds_cptr_f64)us;
         asm volatile("" : "+v"(up));
         double ma[MOMENTS ? T : 1];   // matrix-pipe operands of the chain quad being folded
+        double ms = 0.0;              // ... and the strip rows' operand
         static_for<NB>([&](auto bc) {
             constexpr int b = decltype(bc)::value;
             // U rows 4b..4b+3 are consumed in pieces of kPiece columns; the LDS reads of a
@@ -524,10 +544,22 @@ __global__ void __launch_bounds__(kWave, 2) step_kernel(const StepParams p) {
                                 ma[t] = xs[xrow[t] + 4 * kk] - c0r[t];
                                 if (16 * t + 15 > DP) ma[t] = (16 * t + (lane & 15) <= DP) ? ma[t] : 0.0;   // rows past the ones row
                             }
+                            if constexpr (STRIP) {
+                                ms = xs[xsrow + 4 * kk] - c0s;
+                                ms = (16 * Geo<DP>::T16 + (lane & 3) <= DP) ? ms : 0.0;
+                            }
                         }
-                        constexpr int ti = tile_row(tile), tj = tile - ti * (ti + 1) / 2;
-                        acc[tile] = __builtin_amdgcn_mfma_f64_16x16x4f64(ma[ti], ma[tj], acc[tile], 0, 0, 0);
-                        asm volatile("" : "+a"(acc[tile]));   // keeps the instruction in this piece
+                        if constexpr (!STRIP || tile < NT16) {
+                            constexpr int ti = tile_row(tile), tj = tile - ti * (ti + 1) / 2;
+                            acc[tile] = __builtin_amdgcn_mfma_f64_16x16x4f64(ma[ti], ma[tj], acc[tile], 0, 0, 0);
+                            asm volatile("" : "+a"(acc[tile]));   // keeps the instruction in this piece
+                        } else {
+                            // A: strip rows (lane & 3) x chains (lane >> 4), the same for the four blocks;
+                            // B: the column operand of tile column t, block (lane >> 2) & 3
+                            constexpr int t = tile - NT16;
+                            accs[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(ms, ma[t], accs[t], 0, 0, 0);
+                            asm volatile("" : "+a"(accs[t]));
+                        }
                     });
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -562,10 +594,14 @@ __global__ void __launch_bounds__(kWave, 2) step_kernel(const StepParams p) {
 
     if constexpr (MOMENTS) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+        for (int t = 0; t < NT16; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 p.gacc[(((size_t)group * NT + t) * 4 + r) * kWave + lane] = acc[t][r];
+        if constexpr (STRIP) {
+#pragma unroll
+            for (int t = 0; t < T; ++t) p.gacc[(((size_t)group * NT + NT16 + t) * 4) * kWave + lane] = accs[t];
+        }
     }
     if (active) {
 #pragma unroll

@@ -55,6 +55,20 @@ __global__ void __launch_bounds__(64) mfma_chain_kernel(int K, const double* __r
     for (int r = 0; r < 4; ++r) c[((lane >> 4) + 4 * r) * 16 + (lane & 15)] = acc[r];
 }
 
+// c[4][16] = sum_k a[4][K] b[K][16] with v_mfma_f64_4x4x4_4b_f64: four 4x4 blocks per instruction,
+// block blk = (lane >> 2) & 3 covering columns 4 blk .. 4 blk + 3, the same four rows for every block.
+__global__ void __launch_bounds__(64) mfma_strip_kernel(int K, const double* __restrict__ a,
+                                                        const double* __restrict__ b, double* __restrict__ c) {
+    const int lane = threadIdx.x;
+    double acc = 0.0;
+    for (int k0 = 0; k0 < K; k0 += 4) {
+        const double av = a[(lane & 3) * K + k0 + (lane >> 4)];     // A[i = lane&3][k = lane>>4], any block
+        const double bv = b[(k0 + (lane >> 4)) * 16 + (lane & 15)]; // B[k = lane>>4][j = lane&15]
+        acc = __builtin_amdgcn_mfma_f64_4x4x4f64(av, bv, acc, 0, 0, 0);
+    }
+    c[(lane >> 4) * 16 + (lane & 15)] = acc;                        // D[i = lane>>4][j = lane&15]
+}
+
 }  // namespace
 
 #define ST_TRY(expr)                                   \
@@ -103,6 +117,27 @@ extern "C" int smcmc_selftest_mfma(int device, int K, const double* a, const dou
     ST_TRY(hipGetLastError());
     ST_TRY(hipDeviceSynchronize());
     ST_TRY(hipMemcpy(c, dc, sizeof(double) * 256, hipMemcpyDeviceToHost));
+done:
+    (void)hipFree(da); (void)hipFree(db); (void)hipFree(dc);
+    return rc;
+}
+
+extern "C" int smcmc_selftest_mfma_strip(int device, int K, const double* a, const double* b, double* c) {
+    if (K <= 0 || (K & 3) || !a || !b || !c) return SMCMC_ERR_INVALID;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return SMCMC_ERR_NO_DEVICE;
+    int rc = SMCMC_OK;
+    double *da = nullptr, *db = nullptr, *dc = nullptr;
+    ST_TRY(hipSetDevice(device));
+    ST_TRY(hipMalloc(&da, sizeof(double) * 4 * (size_t)K));
+    ST_TRY(hipMalloc(&db, sizeof(double) * 16 * (size_t)K));
+    ST_TRY(hipMalloc(&dc, sizeof(double) * 64));
+    ST_TRY(hipMemcpy(da, a, sizeof(double) * 4 * (size_t)K, hipMemcpyHostToDevice));
+    ST_TRY(hipMemcpy(db, b, sizeof(double) * 16 * (size_t)K, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(mfma_strip_kernel, dim3(1), dim3(64), 0, nullptr, K, da, db, dc);
+    ST_TRY(hipGetLastError());
+    ST_TRY(hipDeviceSynchronize());
+    ST_TRY(hipMemcpy(c, dc, sizeof(double) * 64, hipMemcpyDeviceToHost));
 done:
     (void)hipFree(da); (void)hipFree(db); (void)hipFree(dc);
     return rc;

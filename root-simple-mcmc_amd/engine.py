@@ -287,6 +287,16 @@ def selftest_mfma(a, b, device=0):
     return c
 
 
+def selftest_mfma_strip(a, b, device=0):
+    lib = _capi.load()
+    a, b = _f64(a), _f64(b)
+    c = np.zeros((4, 16))
+    st = lib.smcmc_selftest_mfma_strip(device, a.shape[1], _ptr(a), _ptr(b), _ptr(c))
+    if st != _capi.OK:
+        raise SmcmcError(st, lib.smcmc_status_string(st).decode())
+    return c
+
+
 class HmcEngine:
     """N independent sMCMC::TSimpleHMC chains (reference TSimpleHMC.H:119-973) with the
     analytic gradient of a device likelihood, fixed |epsilon| and leapfrog count."""

@@ -113,6 +113,27 @@ def test_mfma_f64_is_an_ascending_k_fma_chain(gpu):
     assert np.array_equal(c, ref)
 
 
+def test_mfma_f64_4x4x4_is_an_ascending_k_fma_chain_too(gpu):
+    """The 4x4x4 four-block form that folds the last rows of the D = 50 moments: same order."""
+    import ctypes
+    libm = ctypes.CDLL("libm.so.6")
+    libm.fma.restype = ctypes.c_double
+    libm.fma.argtypes = [ctypes.c_double] * 3
+    rng = np.random.default_rng(4)
+    K = 64
+    a = rng.standard_normal((4, K)) * np.exp(rng.uniform(-8, 8, (4, K)))
+    b = rng.standard_normal((K, 16)) * np.exp(rng.uniform(-8, 8, (K, 16)))
+    c = gpu.selftest_mfma_strip(a, b)
+    ref = np.zeros((4, 16))
+    for i in range(4):
+        for j in range(16):
+            s = 0.0
+            for k in range(K):
+                s = libm.fma(a[i, k], b[k, j], s)
+            ref[i, j] = s
+    assert np.array_equal(c, ref)
+
+
 # ---------------------------------------------------------------- frozen mode
 @pytest.mark.parametrize("dim,nchains,steps", [(2, 1, 300), (5, 70, 400), (7, 64, 200), (8, 130, 150),
                                                 (20, 65, 120), (50, 128, 60), (63, 64, 30)])

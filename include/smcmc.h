@@ -224,6 +224,10 @@ const char* smcmc_hmc_last_error(const smcmc_hmc* h);
 int smcmc_hmc_set_stream(smcmc_hmc* h, void* hip_stream);
 int smcmc_hmc_set_likelihood_params(smcmc_hmc* h, const double* params, int count);   /* GetLogLikelihood :157 */
 int smcmc_hmc_set_alpha(smcmc_hmc* h, double alpha);                     /* SetAlpha :175 */
+/* 1 (default): the reference's operation order throughout.  0: the gradient of the quadratic-form
+ * likelihood (TDummyLogLikelihood.H:34-42) sums its terms in the same order with one fused multiply-add
+ * each, on the FP64 matrix pipe (dim <= 512); nothing else changes.  Before smcmc_hmc_start. */
+int smcmc_hmc_set_exact_arithmetic(smcmc_hmc* h, int exact);
 int smcmc_hmc_set_mean_epsilon(smcmc_hmc* h, double epsilon);            /* SetMeanEpsilon :181 (after Start, which resets it to 0.05) */
 int smcmc_hmc_get_mean_epsilon(smcmc_hmc* h, double* epsilon);           /* GetMeanEpsilon :184 */
 int smcmc_hmc_set_leapfrog(smcmc_hmc* h, int steps);                     /* SetLeapFrog :190 */

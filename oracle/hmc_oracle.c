@@ -28,6 +28,16 @@ static int hmc_grad_quadform(int n, double* g, const double* p, const double* E)
     }
     return 1;
 }
+/* the same sum, same order, one fused multiply-add per term: the engine's fused order
+ * (smcmc_hmc_set_exact_arithmetic(h, 0)), what a chain of v_mfma_f64_16x16x4_f64 computes */
+static int hmc_grad_quadform_fused(int n, double* g, const double* p, const double* E) {
+    for (int i = 0; i < n; ++i) {
+        double s = 0.0;
+        for (int j = 0; j < n; ++j) s = SMCMC_FMA(E[i * n + j], p[j], s);
+        g[i] = -s;
+    }
+    return 1;
+}
 /* THardLogLikelihood.H:70-91 */
 static int hmc_grad_rosenbrock(int n, double* g, const double* p, double rb) {
     g[0] = -2.0 * (1.0 - p[0]) - 4.0 * rb * p[0] * (p[1] - p[0] * p[0]);
@@ -56,6 +66,7 @@ typedef struct {
     double* central; double central_potential;
     int last_accept;
     int potential_from_gradient;   /* 1: the HIP engine's association of the quadratic-form potential */
+    int fused_gradient;            /* 1: quadratic-form gradient with fused multiply-adds */
 } oracle_hmc;
 
 static double hmc_potential(oracle_hmc* h, const double* p) {               /* :411-414 */
@@ -66,7 +77,8 @@ static double hmc_potential(oracle_hmc* h, const double* p) {               /* :
          * sum, TDummyLogLikelihood.H:24-28, is serial per chain) */
         const int n = h->dim;
         double* g = (double*)malloc(sizeof(double) * (size_t)n);
-        hmc_grad_quadform(n, g, p, h->like_params);          /* g = -Error q */
+        if (h->fused_gradient) hmc_grad_quadform_fused(n, g, p, h->like_params);
+        else hmc_grad_quadform(n, g, p, h->like_params);     /* g = -Error q */
         double usum = 0.0;
         for (int i = 0; i < n; ++i) usum += 0.5 * p[i] * (-g[i]);
         free(g);
@@ -80,7 +92,10 @@ static void hmc_potential_gradient(oracle_hmc* h, double* grad, const double* p)
     ++h->gradient_count;
     switch (h->like_kind) {
         case ORACLE_LIKE_ISO: hmc_grad_iso(h->dim, grad, p); break;
-        case ORACLE_LIKE_QUADFORM: hmc_grad_quadform(h->dim, grad, p, h->like_params); break;
+        case ORACLE_LIKE_QUADFORM:
+            if (h->fused_gradient) hmc_grad_quadform_fused(h->dim, grad, p, h->like_params);
+            else hmc_grad_quadform(h->dim, grad, p, h->like_params);
+            break;
         default: hmc_grad_rosenbrock(h->dim, grad, p, h->like_params ? h->like_params[0] : 100.0); break;
     }
     for (int i = 0; i < h->dim; ++i) grad[i] = -grad[i];
@@ -124,6 +139,7 @@ void oracle_hmc_set_alpha(oracle_hmc* h, double a) { h->alpha = a; }            
 void oracle_hmc_set_mean_epsilon(oracle_hmc* h, double e) { h->mean_epsilon = e; }   /* :181 */
 void oracle_hmc_set_leapfrog(oracle_hmc* h, int n) { h->leapfrog_steps = -n; }       /* :190 */
 void oracle_hmc_set_potential_from_gradient(oracle_hmc* h, int f) { h->potential_from_gradient = f; }
+void oracle_hmc_set_fused_gradient(oracle_hmc* h, int f) { h->fused_gradient = f; }
 
 /* Start :210-269 (the covariance bookkeeping is not restated: with a negative mean
  * epsilon and SetLeapFrog the chain never reads it) */

@@ -126,6 +126,7 @@ def _declare(L):
     L.oracle_hmc_set_mean_epsilon.argtypes = [C.c_void_p, C.c_double]
     L.oracle_hmc_set_leapfrog.argtypes = [C.c_void_p, C.c_int]
     L.oracle_hmc_set_potential_from_gradient.argtypes = [C.c_void_p, C.c_int]
+    L.oracle_hmc_set_fused_gradient.argtypes = [C.c_void_p, C.c_int]
     L.oracle_hmc_start.argtypes = [C.c_void_p, _dp]
     L.oracle_hmc_step.restype = C.c_int
     L.oracle_hmc_step.argtypes = [C.c_void_p]
@@ -410,11 +411,13 @@ HMC_SCALARS = ["accepted_potential", "proposed_potential", "current_acceptance",
 class Hmc:
     """One reference HMC chain: sMCMC::TSimpleHMC<L, analytic gradient>."""
 
-    def __init__(self, dim, kind=LIKE_ISO, params=None, seed=20240607, chain_id=0, potential_from_gradient=False):
+    def __init__(self, dim, kind=LIKE_ISO, params=None, seed=20240607, chain_id=0, potential_from_gradient=False,
+                 fused_gradient=False):
         self.dim = dim
         prm = like_params(kind, dim, params)
         self._h = lib().oracle_hmc_create(dim, kind, _p(prm) if prm.size else None, prm.size, seed, chain_id)
         lib().oracle_hmc_set_potential_from_gradient(self._h, int(potential_from_gradient))
+        lib().oracle_hmc_set_fused_gradient(self._h, int(fused_gradient))
 
     def __del__(self):
         if getattr(self, "_h", None):

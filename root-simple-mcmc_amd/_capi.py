@@ -88,6 +88,7 @@ SIGNATURES = {
     "smcmc_hmc_last_error": (C.c_char_p, [_H]),
     "smcmc_hmc_set_stream": (C.c_int, [_H, C.c_void_p]),
     "smcmc_hmc_set_likelihood_params": (C.c_int, [_H, _dp, C.c_int]),
+    "smcmc_hmc_set_exact_arithmetic": (C.c_int, [_H, C.c_int]),
     "smcmc_hmc_set_alpha": (C.c_int, [_H, C.c_double]),
     "smcmc_hmc_set_mean_epsilon": (C.c_int, [_H, C.c_double]),
     "smcmc_hmc_get_mean_epsilon": (C.c_int, [_H, _dp]),

@@ -3,6 +3,7 @@
 // TSimpleHMC.H:119-973) for a fixed step length and leapfrog count.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <new>
@@ -11,6 +12,7 @@
 
 #include "smcmc.h"
 #include "smcmc_hmc_kernel.hip.h"
+#include "smcmc_hmc_mfma_kernel.hip.h"
 
 using namespace smcmc;
 
@@ -19,6 +21,8 @@ struct smcmc_hmc {
     uint64_t seed = 0;
     uint32_t chain_offset = 0, step_count = 0;
     bool started = false;
+    bool exact = true;             // false: fused order, the quadratic-form gradient on the matrix pipe
+    bool use_mfma = false;
     double alpha = 0.0;            // fAlpha, TSimpleHMC.H:133
     double mean_epsilon = 0.05;    // fMeanEpsilon, set by Start (:229)
     int leapfrog = 10;             // fLeapFrogSteps (:133); SetLeapFrog(n) stores -n (:190)
@@ -59,6 +63,7 @@ HmcParams hmc_params(smcmc_hmc* h, int nsteps, int init_only) {
 }
 
 hipError_t hmc_dispatch(smcmc_hmc* h, const HmcParams& p) {
+    if (h->use_mfma) return launch_hmc_mfma(p, h->stream);
     return (h->W == 4) ? launch_hmc<4, kPanelCW>(p, h->likelihood, h->stream)
                        : launch_hmc<8, kPanelCW>(p, h->likelihood, h->stream);
 }
@@ -91,7 +96,8 @@ int smcmc_hmc_create(int dim, int nchains, int likelihood, uint64_t seed, uint32
     HMC_TRY(h, hipMalloc(&h->d_pm, vec));
     HMC_TRY(h, hipMalloc(&h->d_qn, vec));
     HMC_TRY(h, hipMalloc(&h->d_pn, vec));
-    HMC_TRY(h, hipMalloc(&h->d_E, sizeof(double) * (size_t)h->W * dim * kPanelCW));
+    const size_t e_doubles = std::max((size_t)h->W * dim * kPanelCW, hmc_mfma_eop_doubles(dim));
+    HMC_TRY(h, hipMalloc(&h->d_E, sizeof(double) * e_doubles));
     HMC_TRY(h, hipMalloc(&h->d_like, sizeof(double) * 8));
     HMC_TRY(h, hipMalloc(&h->d_lane_f64, sizeof(double) * (size_t)h->npad * SMCMC_LANE_F64_COUNT_));
     HMC_TRY(h, hipMalloc(&h->d_lane_i32, sizeof(int32_t) * (size_t)h->npad * SMCMC_LANE_I32_COUNT_));
@@ -99,7 +105,7 @@ int smcmc_hmc_create(int dim, int nchains, int likelihood, uint64_t seed, uint32
     HMC_TRY(h, hipMemset(h->d_pm, 0, vec));
     HMC_TRY(h, hipMemset(h->d_qn, 0, vec));
     HMC_TRY(h, hipMemset(h->d_pn, 0, vec));
-    HMC_TRY(h, hipMemset(h->d_E, 0, sizeof(double) * (size_t)h->W * dim * kPanelCW));
+    HMC_TRY(h, hipMemset(h->d_E, 0, sizeof(double) * e_doubles));
     HMC_TRY(h, hipMemset(h->d_like, 0, sizeof(double) * 8));
     HMC_TRY(h, hipMemset(h->d_lane_f64, 0, sizeof(double) * (size_t)h->npad * SMCMC_LANE_F64_COUNT_));
     HMC_TRY(h, hipMemset(h->d_lane_i32, 0, sizeof(int32_t) * (size_t)h->npad * SMCMC_LANE_I32_COUNT_));
@@ -132,6 +138,12 @@ int smcmc_hmc_set_likelihood_params(smcmc_hmc* h, const double* params, int coun
     return SMCMC_OK;
 }
 
+int smcmc_hmc_set_exact_arithmetic(smcmc_hmc* h, int exact) {
+    if (!h) return SMCMC_ERR_INVALID;
+    if (h->started) return hfail(h, SMCMC_ERR_LOGIC, "choose the arithmetic before Start");
+    h->exact = exact != 0;
+    return SMCMC_OK;
+}
 int smcmc_hmc_set_alpha(smcmc_hmc* h, double a) { if (!h) return SMCMC_ERR_INVALID; h->alpha = a; return SMCMC_OK; }
 int smcmc_hmc_set_mean_epsilon(smcmc_hmc* h, double e) { if (!h) return SMCMC_ERR_INVALID; h->mean_epsilon = e; return SMCMC_OK; }
 int smcmc_hmc_set_leapfrog(smcmc_hmc* h, int n) { if (!h) return SMCMC_ERR_INVALID; h->leapfrog = -n; return SMCMC_OK; }
@@ -145,6 +157,21 @@ int smcmc_hmc_start(smcmc_hmc* h, const double* x0, int broadcast) {
     if (h->likelihood == SMCMC_LIKE_QUADFORM) {
         if ((int)h->like_params.size() != D * D)
             return hfail(h, SMCMC_ERR_INVALID, "QUADFORM needs dim*dim likelihood parameters (the Error matrix)");
+        h->use_mfma = !h->exact && D <= kMfDimMax;
+        if (h->use_mfma) {
+            // Eop[(tile * nkq + kq) * 64 + lane] = Error(16 tile + (lane & 15), 4 kq + (lane >> 4)): the A operand
+            // of every matrix instruction as one contiguous 512-byte read
+            const int ntiles = (D + 15) / 16, nkq = (D + 3) / 4;
+            std::vector<double> eop(hmc_mfma_eop_doubles(D), 0.0);
+            for (int it = 0; it < ntiles; ++it)
+                for (int kq = 0; kq < nkq; ++kq)
+                    for (int l = 0; l < 64; ++l) {
+                        const int i = 16 * it + (l & 15), j = 4 * kq + (l >> 4);
+                        if (i < D && j < D) eop[((size_t)it * nkq + kq) * 64 + l] = h->like_params[(size_t)i * D + j];
+                    }
+            HMC_TRY(h, hipMemcpyAsync(h->d_E, eop.data(), eop.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+            HMC_TRY(h, hipStreamSynchronize(h->stream));
+        }
         // Eperm[w][j][il] = Error(il*W + w, j): the rows a wavefront owns, contiguous per source column j
         std::vector<double> perm((size_t)W * D * kPanelCW, 0.0);
         for (int w = 0; w < W; ++w)
@@ -153,8 +180,12 @@ int smcmc_hmc_start(smcmc_hmc* h, const double* x0, int broadcast) {
                     const int i = il * W + w;
                     if (i < D) perm[((size_t)w * D + j) * kPanelCW + il] = h->like_params[(size_t)i * D + j];
                 }
-        HMC_TRY(h, hipMemcpyAsync(h->d_E, perm.data(), perm.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
-        HMC_TRY(h, hipStreamSynchronize(h->stream));
+        if (!h->use_mfma) {
+            HMC_TRY(h, hipMemcpyAsync(h->d_E, perm.data(), perm.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+            HMC_TRY(h, hipStreamSynchronize(h->stream));
+        }
+    } else {
+        h->use_mfma = false;
     }
     double b = 100.0;
     if (h->likelihood == SMCMC_LIKE_ROSENBROCK && !h->like_params.empty()) b = h->like_params[0];

@@ -1,0 +1,325 @@
+// smcmc_hmc_mfma_kernel.hip.h -- TSimpleHMC::Step() for the quadratic-form likelihood with the
+// gradient contraction on the FP64 matrix pipe.
+//
+// Same chain as hmc_step_kernel (smcmc_hmc_kernel.hip.h; reference TSimpleHMC.H:279-401,
+// 554-570, 582-651) except for ONE thing, which the engine calls the fused order
+// (SMCMC_P_EXACT_ARITHMETIC = 0 of the HMC engine, mirrored by oracle/hmc_oracle.c): the
+// gradient g_i = sum_j Error(i,j) q_j (TDummyLogLikelihood.H:34-42) accumulates j in the
+// reference's ascending order but with one fused multiply-add per term, which is what a chain
+// of v_mfma_f64_16x16x4_f64 does (tests/test_gpu_parity.py pins that order on the hardware).
+// Everything else -- momentum refresh, leapfrog updates, kinetic energy and potential summed in
+// dimension order, Hamiltonian test -- keeps the reference's operations.
+//
+// Layout: a workgroup of 8 wavefronts advances 32 chains (two 16-chain tiles); the work of a
+// trajectory is the 21 products  G[512 x 32] = Error[512 x 512] . Q[512 x 32].  A matrix
+// instruction produces D[row = component][col = chain]; lane l holds column l & 15 and rows
+// (l >> 4) + 4 r.  Positions, momenta and gradients stay in registers in exactly that layout
+// (wavefront w owns the component tiles w, w + 8, ...), so the leapfrog updates are register to
+// register.  Only Q has to be seen by everybody: it is published to LDS as q[component][chain]
+// (128 KB) before every gradient, from where the B operand of k-quad kq is the row quad
+// 4 kq .. 4 kq + 3.  Error comes from L2 in operand order (Eop[tile][kq][lane], one coalesced
+// 512-byte read per instruction, laid out by the host).  Sums the reference runs over all
+// components in index order (kinetic energy, potential) are formed term by term in registers,
+// published through the same LDS array and added up in order by one lane per chain.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "smcmc.h"
+#include "smcmc_detmath.h"
+#include "smcmc_hmc_kernel.hip.h"
+
+namespace smcmc {
+
+constexpr int kMfCT = 32;                            // chains per workgroup
+constexpr int kMfW = 8;                              // wavefronts per workgroup
+constexpr int kMfTIMax = 4;                          // 16-component tiles per wavefront: dim <= 512
+constexpr int kMfDimMax = 16 * kMfW * kMfTIMax;
+
+// Eop[(tile * nkq + kq) * 64 + lane] = Error(16 tile + (lane & 15), 4 kq + (lane >> 4)), zero padded
+inline size_t hmc_mfma_eop_doubles(int dim) {
+    const int ntiles = (dim + 15) / 16, nkq = (dim + 3) / 4;
+    return (size_t)ntiles * nkq * 64;
+}
+
+// TI = 16-component tiles a wavefront owns: dim <= 128 TI
+template <int kMfTI>
+__global__ void __launch_bounds__(kMfW* kWave, 1) hmc_mfma_kernel(const HmcParams p) {
+    __shared__ double qs[16 * kMfW * kMfTI * kMfCT];   // [component][chain]: the published vector
+    __shared__ double red0[kMfCT], red1[kMfCT];
+    __shared__ int verdict[kMfCT];
+
+    const int lane = threadIdx.x & (kWave - 1);
+    const int w = threadIdx.x / kWave;
+    const int c = lane & 15, rq = lane >> 4;
+    const int base = blockIdx.x * kMfCT;
+    const int D = p.dim;
+    // the row stride is re-read through an opaque copy every step: otherwise the 96 element addresses of
+    // q, pm and qn are hoisted out of the step loop as 64-bit values and spilled
+    size_t NP = (size_t)p.npad;
+    const int ntiles = (D + 15) / 16, nkq = (D + 3) / 4;
+    const uint32_t ew = smcmc_accept_word((uint32_t)D);
+
+    // this lane's chains (one per chain tile) and, for the summing lanes of wavefront 0, `mychain`
+    const bool summer = (w == 0) && (lane < kMfCT);
+    const int mychain = base + lane;
+
+    typedef double f64x4v __attribute__((ext_vector_type(4)));
+    f64x4v pn[kMfTI][2], gr[kMfTI][2];   // momenta and gradients of the owned elements; positions live in qs
+
+    // element (t, ct, r): component 16 (t W + w) + 4 r + rq of chain base + 16 ct + c
+    auto comp = [&](int t, int r) { return 16 * (t * kMfW + w) + 4 * r + rq; };
+    auto owns = [&](int t) { return t * kMfW + w < ntiles; };
+    auto slot = [&](int t, int ct, int r) { return comp(t, r) * kMfCT + 16 * ct + c; };
+
+    // v[t][ct][r] -> qs[component][chain]; rows past D (inside the owned tiles) carry zeros
+    auto publish = [&](auto&& value) {
+        __syncthreads();   // readers of the previous contents are done
+#pragma unroll
+        for (int t = 0; t < kMfTI; ++t) {
+            if (!owns(t)) continue;
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) qs[slot(t, ct, r)] = (comp(t, r) < D) ? value(t, ct, r) : 0.0;
+        }
+        __syncthreads();
+    };
+    // sum of the published column of every chain, components in ascending order (one lane per chain)
+    auto ordered_sum = [&]() {
+        double s = 0.0;
+        if (summer)
+            for (int i = 0; i < D; ++i) s += qs[i * kMfCT + lane];
+        return s;
+    };
+
+    // gr = Error q for the owned components, q = the positions in qs (PotentialGradient,
+    // TSimpleHMC.H:467-492, for the quadratic form of TDummyLogLikelihood.H:34-42)
+    auto gradient = [&]() {
+        __syncthreads();   // every owner has written its positions
+#pragma unroll
+        for (int t = 0; t < kMfTI; ++t)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) gr[t][ct] = f64x4v{0.0, 0.0, 0.0, 0.0};
+        const double* eop = p.Eperm + lane;
+        for (int kq = 0; kq < nkq; ++kq) {
+            const double b0 = qs[(4 * kq + rq) * kMfCT + c];
+            const double b1 = qs[(4 * kq + rq) * kMfCT + 16 + c];
+#pragma unroll
+            for (int t = 0; t < kMfTI; ++t) {
+                if (!owns(t)) continue;
+                const double a = eop[((size_t)(t * kMfW + w) * nkq + kq) * 64];
+                gr[t][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0, gr[t][0], 0, 0, 0);
+                gr[t][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b1, gr[t][1], 0, 0, 0);
+            }
+        }
+        __syncthreads();   // the positions may be overwritten again
+    };
+
+    // potential of the positions in qs from their gradient (the engine's association, see
+    // hmc_step_kernel): U = sum_i 0.5 q_i (Error q)_i in dimension order.  The positions are parked
+    // in the proposal buffer qn (HBM) first, because the sum goes through qs.
+    auto potential = [&]() {
+#pragma unroll
+        for (int t = 0; t < kMfTI; ++t)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = comp(t, r);
+                    if (owns(t) && i < D) {
+                        const double qv = qs[slot(t, ct, r)];
+                        p.qn[(size_t)i * NP + base + 16 * ct + c] = qv;
+                        gr[t][ct][r] = 0.5 * qv * gr[t][ct][r];
+                    }
+                }
+        publish([&](int t, int ct, int r) { return gr[t][ct][r]; });
+        return ordered_sum();
+    };
+    auto kinetic = [&]() {   // KineticEnergy (:535-542): ke += p*p/2.0
+        publish([&](int t, int ct, int r) { return pn[t][ct][r] * pn[t][ct][r] / 2.0; });
+        return ordered_sum();
+    };
+
+    // per-chain state lives in the summing lanes
+    double pot_acc = 0.0, pot_prop = 0.0, acceptance = 0.0;
+    int naccept = 0, last_accept = 0, trials = 0;
+    if (summer) {
+        pot_acc = -p.lane_f64[SMCMC_LANE_LOGL * NP + mychain];
+        pot_prop = -p.lane_f64[SMCMC_LANE_LOGL_PROPOSED * NP + mychain];
+        acceptance = p.lane_f64[SMCMC_LANE_ACCEPTANCE * NP + mychain];
+        naccept = p.lane_i32[SMCMC_LANE_NACCEPT * NP + mychain];
+        last_accept = p.lane_i32[SMCMC_LANE_LAST_ACCEPT * NP + mychain];
+        trials = p.lane_i32[SMCMC_LANE_TRIALS * NP + mychain];
+    }
+
+    // positions of the accepted point into qs (LeapFrog: qNew = position, :586)
+    auto load_q = [&]() {
+        publish([&](int t, int ct, int r) { return p.q[(size_t)comp(t, r) * NP + base + 16 * ct + c]; });
+    };
+
+    if (p.init_only) {
+        // Start (:210-269): SetPosition's Potential(start) for every chain
+        load_q();
+        gradient();
+        const double u0 = potential();
+        if (summer && mychain < p.nchains) {
+            p.lane_f64[SMCMC_LANE_LOGL * NP + mychain] = -u0;
+            p.lane_f64[SMCMC_LANE_LOGL_PROPOSED * NP + mychain] = -u0;
+        }
+        return;
+    }
+
+    for (int s = 0; s < p.nsteps; ++s) {
+        const uint64_t step = (uint64_t)(p.step0 + (uint32_t)s + 1u);   // ++fStepCount, :286
+        ++trials;
+        asm volatile("" : "+s"(NP));
+
+        // ---- ProposeMomentum (:554-570) ----
+        const double mix = __builtin_sqrt(1.0 - p.alpha * p.alpha);
+        double eps[2];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            const uint32_t gid = p.chain_offset + (uint32_t)(base + 16 * ct + c);
+#pragma unroll
+            for (int t = 0; t < kMfTI; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = comp(t, r);
+                    double v = 0.0;
+                    if (owns(t) && i < D) {
+                        const double m = p.pm[(size_t)i * NP + base + 16 * ct + c];
+                        if (p.alpha >= 1.0) {
+                            v = m / p.alpha;
+                        } else {
+                            const uint32_t pr = (uint32_t)i >> 1;
+                            smcmc_u32x4 blk = smcmc_draw_block(p.seed, gid, step, pr >> 1, SMCMC_STREAM_HMC);
+                            double n0, n1;
+                            const uint32_t w0 = (pr & 1u) ? blk.v[2] : blk.v[0], w1 = (pr & 1u) ? blk.v[3] : blk.v[1];
+                            smcmc_normal_pair(w0, w1, &n0, &n1);
+                            v = p.alpha * m + mix * ((i & 1) ? n1 : n0);
+                        }
+                    }
+                    pn[t][ct][r] = v;
+                    __builtin_amdgcn_sched_barrier(0);   // one draw at a time: interleaved they exhaust the registers
+                }
+            // ---- epsilon (:297-298) ----
+            const smcmc_u32x4 eblk = smcmc_draw_block(p.seed, gid, step, ew >> 2, SMCMC_STREAM_HMC);
+            const double lo = 0.9 * p.abs_eps, hi = 1.1 * p.abs_eps;
+            eps[ct] = lo + (hi - lo) * smcmc_u01(smcmc_select_word(eblk, ew & 3u));
+        }
+        const double ke0 = kinetic();                                   // :292
+        load_q();
+
+        // ---- LeapFrog (:582-651) ----
+        const int L = p.leapfrog;
+        auto kick = [&](bool half) {                                    // pNew[i] -= eps*grad[i] (/2.0)
+#pragma unroll
+            for (int t = 0; t < kMfTI; ++t)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const double m = pn[t][ct][r];
+                        pn[t][ct][r] = half ? m - eps[ct] * gr[t][ct][r] / 2.0 : m - eps[ct] * gr[t][ct][r];
+                    }
+        };
+        auto drift = [&]() {                                            // qNew[i] += eps*pNew[i]
+#pragma unroll
+            for (int t = 0; t < kMfTI; ++t) {
+                if (!owns(t)) continue;
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (comp(t, r) < D) qs[slot(t, ct, r)] = qs[slot(t, ct, r)] + eps[ct] * pn[t][ct][r];
+                    }
+            }
+        };
+        if (L < 1) {
+            // the one-step shortcut (:598-611): qNew += eps*(momentum + pNew)/2 with pNew == momentum
+#pragma unroll
+            for (int t = 0; t < kMfTI; ++t) {
+                if (!owns(t)) continue;
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const double m = pn[t][ct][r];
+                        if (comp(t, r) < D) qs[slot(t, ct, r)] = qs[slot(t, ct, r)] + eps[ct] * (m + m) / 2.0;
+                    }
+            }
+            gradient();                                                 // for the potential below
+        } else {
+            gradient();                                                 // :615
+            kick(true);                                                 // :618-620
+            for (int ls = 0; ls < L - 1; ++ls) {                        // :623-639
+                drift();
+                gradient();
+                kick(false);
+            }
+            drift();                                                    // :641-643
+            gradient();                                                 // :645
+            kick(true);                                                 // :646-648
+        }
+
+        // ---- proposed potential and kinetic energy (:326-327), dimension order ----
+        const double u1 = potential();
+        const double ke1 = kinetic();
+
+        // ---- Hamiltonian test (:333-387), one lane per chain decides ----
+        if (summer) {
+            const uint32_t gid = p.chain_offset + (uint32_t)mychain;
+            const smcmc_u32x4 ablk = smcmc_draw_block(p.seed, gid, step, (ew + 1u) >> 2, SMCMC_STREAM_HMC);
+            const double uacc = smcmc_u01(smcmc_select_word(ablk, (ew + 1u) & 3u));
+            pot_prop = u1;
+            const double delta = (pot_prop + ke1) - (pot_acc + ke0);
+            const double trial = -smcmc_log_pos(uacc);
+            const bool reject = (delta > trial) || !__builtin_isfinite(delta) || !(mychain < p.nchains);
+            verdict[lane] = reject ? 0 : 1;
+            if (!reject) {
+                pot_acc = pot_prop;
+                acceptance = (acceptance * 4999.0 + 1.0) / 5000.0;      // :386
+                ++naccept;
+            } else {
+                acceptance = (acceptance * 4999.0) / 5000.0;            // :367
+            }
+            last_accept = reject ? 0 : 1;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            const bool take = verdict[16 * ct + c] != 0;
+            const int chain = base + 16 * ct + c;
+#pragma unroll
+            for (int t = 0; t < kMfTI; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = comp(t, r);
+                    if (owns(t) && i < D && chain < p.nchains) {
+                        if (take) {                                     // :380-383
+                            p.q[(size_t)i * NP + chain] = p.qn[(size_t)i * NP + chain];
+                            p.pm[(size_t)i * NP + chain] = pn[t][ct][r];
+                        } else {                                        // :364-366
+                            p.pm[(size_t)i * NP + chain] = -p.pm[(size_t)i * NP + chain];
+                        }
+                    }
+                }
+        }
+        __syncthreads();
+    }
+
+    if (summer && mychain < p.nchains) {
+        p.lane_f64[SMCMC_LANE_LOGL * NP + mychain] = -pot_acc;
+        p.lane_f64[SMCMC_LANE_LOGL_PROPOSED * NP + mychain] = -pot_prop;
+        p.lane_f64[SMCMC_LANE_ACCEPTANCE * NP + mychain] = acceptance;
+        p.lane_i32[SMCMC_LANE_NACCEPT * NP + mychain] = naccept;
+        p.lane_i32[SMCMC_LANE_LAST_ACCEPT * NP + mychain] = last_accept;
+        p.lane_i32[SMCMC_LANE_TRIALS * NP + mychain] = trials;
+    }
+}
+
+hipError_t launch_hmc_mfma(const HmcParams& p, hipStream_t stream);
+
+}  // namespace smcmc

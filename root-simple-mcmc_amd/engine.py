@@ -302,7 +302,7 @@ class HmcEngine:
     analytic gradient of a device likelihood, fixed |epsilon| and leapfrog count."""
 
     def __init__(self, dim, nchains=1, likelihood=LIKE_ISO_GAUSS, likelihood_params=None, seed=20240607,
-                 chain_offset=0, device=0, stream=None):
+                 chain_offset=0, device=0, stream=None, exact=True):
         self._lib = _capi.load()
         self.dim, self.nchains = int(dim), int(nchains)
         h = C.c_void_p()
@@ -319,6 +319,8 @@ class HmcEngine:
             self._check(self._lib.smcmc_hmc_set_likelihood_params(self._h, _ptr(prm), prm.size))
         if stream is not None:
             self._check(self._lib.smcmc_hmc_set_stream(self._h, C.c_void_p(int(stream))))
+        if not exact:
+            self._check(self._lib.smcmc_hmc_set_exact_arithmetic(self._h, 0))
 
     def _check(self, st):
         if st != _capi.OK:

@@ -12,8 +12,9 @@ def _spd(dim, seed):
     return a @ a.T + np.eye(dim)
 
 
-def _check(gpu, oracle, dim, nchains, kind, params, x0, eps, leap, steps, alpha=0.0, chains=(0, 1, 63, 64)):
-    e = gpu.HmcEngine(dim, nchains, likelihood=kind, likelihood_params=params, seed=99)
+def _check(gpu, oracle, dim, nchains, kind, params, x0, eps, leap, steps, alpha=0.0, chains=(0, 1, 63, 64),
+           exact=True):
+    e = gpu.HmcEngine(dim, nchains, likelihood=kind, likelihood_params=params, seed=99, exact=exact)
     e.SetAlpha(alpha)
     e.Start(x0)
     e.SetMeanEpsilon(-eps)         # fixed step length: fMeanEpsilon < 0 (TSimpleHMC.H:297, 304-343)
@@ -24,7 +25,8 @@ def _check(gpu, oracle, dim, nchains, kind, params, x0, eps, leap, steps, alpha=
     for ch in chains:
         if ch >= nchains:
             continue
-        h = oracle.Hmc(dim, kind=kind, params=params, seed=99, chain_id=ch, potential_from_gradient=True)
+        h = oracle.Hmc(dim, kind=kind, params=params, seed=99, chain_id=ch, potential_from_gradient=True,
+                       fused_gradient=not exact)
         h.set_alpha(alpha)
         h.start(x0 if x0.ndim == 1 else x0[:, ch])
         h.set_mean_epsilon(-eps)
@@ -58,6 +60,31 @@ def test_hmc_quadratic_form_matches_reference_chain(gpu, oracle, dim, nchains, l
     """The D x D gradient contraction of TDummyLogLikelihood.H:34-42 (config 5's hot loop)."""
     err = _spd(dim, dim)
     _check(gpu, oracle, dim, nchains, 1, err, np.ones(dim), 0.05, leap, 6, alpha=0.3)
+
+
+@pytest.mark.parametrize("dim,nchains,leap", [(5, 70, 20), (16, 33, 3), (100, 64, 20), (300, 96, 6), (500, 64, 4),
+                                              (512, 32, 2)])
+def test_hmc_quadratic_form_on_the_matrix_pipe(gpu, oracle, dim, nchains, leap):
+    """Fused order: the gradient contraction as a chain of v_mfma_f64_16x16x4_f64 (32 chains per
+    workgroup, positions / momenta / gradients in the matrix layout), bit for bit the oracle's
+    fused-gradient chain."""
+    err = _spd(dim, dim + 1)
+    rng = np.random.default_rng(dim)
+    x0 = np.ones(dim) if dim % 2 else rng.uniform(0.5, 1.5, (dim, nchains))
+    _check(gpu, oracle, dim, nchains, 1, err, x0, 0.05, leap, 5, alpha=0.3, exact=False,
+           chains=(0, 1, 15, 16, 31, 32, 63, 64, 95))
+
+
+def test_hmc_fused_order_stays_close_to_reference_order(gpu):
+    dim, n = 200, 64
+    err = _spd(dim, 3)
+    out = []
+    for exact in (True, False):
+        e = gpu.HmcEngine(dim, n, likelihood=1, likelihood_params=err, seed=4, exact=exact)
+        e.Start(np.ones(dim)); e.SetMeanEpsilon(-0.02); e.SetLeapFrog(10); e.Step(3)
+        out.append(e.state())
+    assert np.allclose(out[0][0], out[1][0], rtol=1e-9, atol=1e-11)
+    assert np.allclose(out[0][2], out[1][2], rtol=1e-9)
 
 
 def test_hmc_quadform_potential_close_to_reference_order(gpu, oracle):

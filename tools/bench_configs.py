@@ -53,10 +53,12 @@ for name, dim, n, kind, prm in (("config3_rosenbrock_d200_16384_pooled", 200, 16
 # config 5: HMC, header TDummy D=500 (Error from Init()), 8 192 chains x 20 leapfrog steps
 from oracle import oracle as O  # noqa: E402  (only for TDummyLogLikelihood::Init's Error matrix)
 err = O.dummy_error_matrix(500)[1]
-h = pkg.HmcEngine(500, 8192, likelihood=pkg.LIKE_QUADFORM, likelihood_params=err)
-h.Start(np.ones(500)); h.SetMeanEpsilon(-0.0005); h.SetLeapFrog(20)
-dt = timed(lambda: h.Step(2), 2)
-out["config5_hmc_quadform_d500_8192_L20"] = {"trajectories_per_s": 8192 * 2 / dt, "ms_per_step": dt / 2 * 1e3,
-                                             "gradient_GFLOPs": 8192 * 2 / dt * 21 * 2 * 500 * 500 / 1e9,
-                                             "accept": float(h.lane("naccept").mean() / h.lane("trials").mean())}
+for tag, exact, nstep in (("reference_order", True, 2), ("fused_order_matrix_pipe", False, 20)):
+    h = pkg.HmcEngine(500, 8192, likelihood=pkg.LIKE_QUADFORM, likelihood_params=err, exact=exact)
+    h.Start(np.ones(500)); h.SetMeanEpsilon(-0.0005); h.SetLeapFrog(20)
+    dt = timed(lambda: h.Step(nstep), 2)
+    out["config5_hmc_quadform_d500_8192_L20_" + tag] = {
+        "trajectories_per_s": 8192 * nstep / dt, "ms_per_step": dt / nstep * 1e3,
+        "gradient_TFLOPs": 8192 * nstep / dt * 21 * 2 * 500 * 500 / 1e12,
+        "accept": float(h.lane("naccept").mean() / h.lane("trials").mean())}
 print(json.dumps(out, indent=1))

@@ -43,7 +43,8 @@ def _headers():
 
 def _units():
     units = [("smcmc_engine.hip", [], "engine"), ("smcmc_selftest.hip", [], "selftest"),
-             ("smcmc_hmc_engine.hip", [], "hmc_engine"), ("smcmc_hmc_mfma_inst.hip", [], "hmc_mfma")]
+             ("smcmc_hmc_engine.hip", [], "hmc_engine"), ("smcmc_hmc_mfma_inst.hip", [], "hmc_mfma"),
+             ("smcmc_panel_mfma_inst.hip", [], "panel_mfma")]
     for dp in dp_list():
         for like in LIKELIHOODS:
             units.append(("smcmc_inst.hip", [f"-DSMCMC_DP={dp}", f"-DSMCMC_LIKE={like}"], f"inst_dp{dp}_l{like}"))

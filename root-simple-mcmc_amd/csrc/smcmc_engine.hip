@@ -16,6 +16,7 @@
 #include "smcmc.h"
 #include "smcmc_kernels.hip.h"
 #include "smcmc_panel_kernel.hip.h"
+#include "smcmc_panel_mfma_kernel.hip.h"
 #include "smcmc_fold_kernel.hip.h"
 #include "smcmc_proposal.hpp"
 
@@ -86,6 +87,7 @@ struct smcmc_engine {
     double* d_lane_f64 = nullptr;
     int32_t* d_lane_i32 = nullptr;
     double* d_U = nullptr;
+    double* d_Uop = nullptr;       // large dimensions, fused order: U^T in matrix-operand order (smcmc_panel_mfma_kernel.hip.h)
     double* d_like = nullptr;
     double* d_c0 = nullptr;
     double* d_gacc = nullptr;
@@ -158,6 +160,18 @@ int upload_shared(smcmc_engine* h) {
                     if (j < D) perm[((size_t)w * D + i) * kPanelCW + jl] = h->prop->decomp[(size_t)i * D + j];
                 }
         HIP_TRY(h, hipMemcpyAsync(h->d_U, perm.data(), perm.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        if (!h->exact && !h->prop->decompFull) {
+            // Uop[(tile * nkq + kq) * 64 + lane] = U(4 kq + (lane >> 4), 16 tile + (lane & 15))
+            const int ntiles = (D + 15) / 16, nkq = (D + 3) / 4;
+            std::vector<double> uop(panel_mfma_uop_doubles(D), 0.0);
+            for (int jt = 0; jt < ntiles; ++jt)
+                for (int kq = 0; kq < nkq; ++kq)
+                    for (int l = 0; l < 64; ++l) {
+                        const int i = 4 * kq + (l >> 4), j = 16 * jt + (l & 15);
+                        if (i < D && j < D) uop[((size_t)jt * nkq + kq) * 64 + l] = h->prop->decomp[(size_t)i * D + j];
+                    }
+            HIP_TRY(h, hipMemcpyAsync(h->d_Uop, uop.data(), uop.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        }
         HIP_TRY(h, hipMemcpyAsync(h->d_c0, h->prop->centre.data(), (size_t)D * sizeof(double), hipMemcpyHostToDevice,
                                   h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -295,8 +309,15 @@ int launch(smcmc_engine* h, int nsteps, int metropolis, int stride, double* save
             }
             q.nsteps = seg;
             q.step0 = h->total_steps;
-            hipError_t e = (h->panel_w == 4) ? launch_panel<4, kPanelCW>(q, h->likelihood, exact, h->stream)
-                                             : launch_panel<8, kPanelCW>(q, h->likelihood, exact, h->stream);
+            hipError_t e;
+            if (!exact) {
+                q.Uperm = h->d_Uop;   // fused order: the proposal on the matrix pipe
+                e = launch_panel_mfma(q, h->likelihood, h->stream);
+            } else {
+                q.Uperm = h->d_U;
+                e = (h->panel_w == 4) ? launch_panel<4, kPanelCW>(q, h->likelihood, exact, h->stream)
+                                      : launch_panel<8, kPanelCW>(q, h->likelihood, exact, h->stream);
+            }
             if (e != hipSuccess) return fail(h, SMCMC_ERR_HIP, std::string("panel kernel launch: ") + hipGetErrorString(e));
             h->total_steps += (uint32_t)seg;
             done += seg;
@@ -385,6 +406,10 @@ int smcmc_create(int dim, int nchains, int likelihood, uint64_t seed, uint32_t c
     HIP_TRY(h, hipMalloc(&h->d_lane_i32, sizeof(int32_t) * np * SMCMC_LANE_I32_COUNT_));
     HIP_TRY(h, hipMalloc(&h->d_U, sizeof(double) * u_doubles));
     HIP_TRY(h, hipMemset(h->d_U, 0, sizeof(double) * u_doubles));
+    if (panel_w) {
+        HIP_TRY(h, hipMalloc(&h->d_Uop, sizeof(double) * panel_mfma_uop_doubles(dim)));
+        HIP_TRY(h, hipMemset(h->d_Uop, 0, sizeof(double) * panel_mfma_uop_doubles(dim)));
+    }
     HIP_TRY(h, hipMalloc(&h->d_like, sizeof(double) * dp * dp));
     HIP_TRY(h, hipMalloc(&h->d_c0, sizeof(double) * dp));
     HIP_TRY(h, hipMalloc(&h->d_gacc, sizeof(double) * gacc_doubles(h)));
@@ -410,7 +435,7 @@ int smcmc_destroy(smcmc_engine* h) {
         (void)hipStreamSynchronize(h->stream);
     }
     (void)hipFree(h->d_x); (void)hipFree(h->d_forced); (void)hipFree(h->d_uniform); (void)hipFree(h->d_lane_f64); (void)hipFree(h->d_lane_i32);
-    (void)hipFree(h->d_U); (void)hipFree(h->d_like); (void)hipFree(h->d_c0); (void)hipFree(h->d_gacc);
+    (void)hipFree(h->d_U); (void)hipFree(h->d_Uop); (void)hipFree(h->d_like); (void)hipFree(h->d_c0); (void)hipFree(h->d_gacc);
     (void)hipFree(h->d_moments); (void)hipFree(h->d_chunks);
     delete h->prop;
     delete h;
@@ -521,7 +546,9 @@ int smcmc_set_param(smcmc_engine* h, int which, double v) {
             return h->started ? broadcast_lane_i32(h, SMCMC_LANE_NEXT_UPDATE, (int32_t)v) : SMCMC_OK;
         case SMCMC_P_COVARIANCE_TRIALS: P.covTrials = v; return SMCMC_OK;
         case SMCMC_P_CENTER_TRIALS: P.centreTrials = v; return SMCMC_OK;
-        case SMCMC_P_EXACT_ARITHMETIC: h->exact = (v != 0.0); return SMCMC_OK;
+        case SMCMC_P_EXACT_ARITHMETIC:
+            h->exact = (v != 0.0);
+            return h->started ? upload_shared(h) : SMCMC_OK;   // the fused order keeps its own operand image of U
         case SMCMC_P_MOMENT_STRIDE:
             if (v < 1.0) return fail(h, SMCMC_ERR_INVALID, "moment stride must be >= 1");
             if (!h->panel_w && v != 1.0)

@@ -1,0 +1,333 @@
+// smcmc_panel_mfma_kernel.hip.h -- the Metropolis step for 63 < D <= 512 in the fused order
+// (SMCMC_P_EXACT_ARITHMETIC = 0) with the proposal x' = x + sigma U^T r (reference
+// TSimpleMCMC.H:709-724) on the FP64 matrix pipe.
+//
+// The fused order is xp[j] = fma(sigma r_i, U(i,j), xp[j]), i ascending, starting from x[j]: a chain
+// of v_mfma_f64_16x16x4_f64 whose C operand starts as x does exactly that (order pinned on the
+// hardware by tests/test_gpu_parity.py), so the kernel is bit for bit oracle/ensemble_oracle.c with
+// exact = 0, like panel_step_kernel<..., EXACT = false> which it replaces.
+//
+// Layout (the one of hmc_mfma_kernel): a workgroup of 8 wavefronts advances 32 chains; a matrix
+// instruction yields D[row = component j][col = chain]; lane l holds chain l & 15 and components
+// (l >> 4) + 4 r of its tiles; the accepted point and the proposal stay in registers in that layout
+// for the whole launch.  z = sigma r goes to LDS as z[i][chain] (B operand: the row quad 4 kq ..
+// 4 kq + 3); U^T streams from L2 in operand order, Uop[tile][kq][lane] = U(4 kq + (lane >> 4),
+// 16 tile + (lane & 15)), only the k-quads on or above the diagonal (kq <= 4 tile + 3).  Tiles are
+// dealt to the wavefronts in snake order so that the triangular work is balanced.  StepRMS and the
+// likelihood, which sum over all components in index order, are walked by one lane per chain over
+// values published through the same LDS array; those lanes also carry the per-chain scalar state
+// (UpdateState's scalar half, TSimpleMCMC.H:1723-1776) and run the Metropolis test (:410-463).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "smcmc.h"
+#include "smcmc_detmath.h"
+#include "smcmc_panel_kernel.hip.h"
+
+namespace smcmc {
+
+constexpr int kPmCT = 32;   // chains per workgroup
+constexpr int kPmW = 8;     // wavefronts per workgroup
+
+inline size_t panel_mfma_uop_doubles(int dim) {
+    const int ntiles = (dim + 15) / 16, nkq = (dim + 3) / 4;
+    return (size_t)ntiles * nkq * 64;
+}
+
+// TI = 16-component tiles per wavefront: dim <= 128 TI
+template <int TI, int LIKE>
+__global__ void __launch_bounds__(kPmW* kWave, 1) panel_mfma_kernel(const PanelParams p) {
+    __shared__ double qs[16 * kPmW * TI * kPmCT];   // z[i][chain], later the published values of the ordered sums
+    __shared__ double sig[kPmCT], x0s[kPmCT];
+    __shared__ int verdict[kPmCT];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const int w = tid / kWave;
+    const int c = lane & 15, rq = lane >> 4;
+    const int base = blockIdx.x * kPmCT;
+    const int D = p.dim;
+    const size_t NP = (size_t)p.npad;
+    const int ntiles = (D + 15) / 16, nkq = (D + 3) / 4;
+    const uint32_t aw = smcmc_accept_word((uint32_t)D);
+    const double rb = (LIKE == SMCMC_LIKE_ROSENBROCK) ? p.like[0] : 0.0;
+
+    const bool summer = (w == 0) && (lane < kPmCT);   // one lane per chain: scalar state, ordered sums, the test
+    const int mychain = base + lane;
+    const bool active = summer && mychain < p.nchains;
+
+    typedef double f64x4v __attribute__((ext_vector_type(4)));
+    f64x4v x[TI][2], xp[TI][2];
+
+    // tile of slot t of this wavefront, snake order: 0..7, 15..8, 16..23, 31..24
+    auto tile = [&](int t) { return t * kPmW + ((t & 1) ? (kPmW - 1 - w) : w); };
+    auto owns = [&](int t) { return tile(t) < ntiles; };
+    auto comp = [&](int t, int r) { return 16 * tile(t) + 4 * r + rq; };
+    auto slot = [&](int t, int ct, int r) { return comp(t, r) * kPmCT + 16 * ct + c; };
+
+    auto publish = [&](auto&& value) {
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < TI; ++t) {
+            if (!owns(t)) continue;
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) qs[slot(t, ct, r)] = (comp(t, r) < D) ? value(t, ct, r) : 0.0;
+        }
+        __syncthreads();
+    };
+
+    // per-chain scalar state (summing lanes)
+    double logl = 0, sigma = 0, acc_rate = 0, acc_trials = 0, rigid = 0, last_value = 0, last_x0 = 0, step_rms = 0,
+           logl_prop = 0;
+    int trials = 0, succ = 0, next_update = 0, naccept = 0, rms_trials = 0, last_accept = 0;
+    if (summer) {
+        const double* lf = p.lane_f64 + mychain;
+        const int32_t* li = p.lane_i32 + mychain;
+        logl = lf[SMCMC_LANE_LOGL * NP];
+        sigma = lf[SMCMC_LANE_SIGMA * NP];
+        acc_rate = lf[SMCMC_LANE_ACCEPTANCE * NP];
+        acc_trials = lf[SMCMC_LANE_ACCEPTANCE_TRIALS * NP];
+        rigid = lf[SMCMC_LANE_RIGIDITY * NP];
+        last_value = lf[SMCMC_LANE_LAST_VALUE * NP];
+        last_x0 = lf[SMCMC_LANE_LAST_X0 * NP];
+        step_rms = lf[SMCMC_LANE_STEP_RMS * NP];
+        logl_prop = lf[SMCMC_LANE_LOGL_PROPOSED * NP];
+        trials = li[SMCMC_LANE_TRIALS * NP];
+        succ = li[SMCMC_LANE_SUCCESSES * NP];
+        next_update = li[SMCMC_LANE_NEXT_UPDATE * NP];
+        naccept = li[SMCMC_LANE_NACCEPT * NP];
+        rms_trials = li[SMCMC_LANE_STEP_RMS_TRIALS * NP];
+        last_accept = li[SMCMC_LANE_LAST_ACCEPT * NP];
+        sigma = sigma * p.pending_sigma_scale;
+        if (p.pending_deweight && p.acc_w >= 0.0) {
+            acc_trials = dmax(1.0, p.acc_w * acc_trials);
+            acc_trials = dmin(acc_trials, p.acc_wW);
+        }
+        x0s[lane] = p.x[mychain];
+    }
+
+    // the accepted point, matrix layout
+#pragma unroll
+    for (int t = 0; t < TI; ++t)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = comp(t, r);
+                x[t][ct][r] = (owns(t) && i < D) ? p.x[(size_t)i * NP + base + 16 * ct + c] : 0.0;
+            }
+    // rows of z past D stay zero for the whole launch
+    for (int k = tid; k < 16 * kPmW * TI * kPmCT; k += kPmW * kWave) qs[k] = 0.0;
+    __syncthreads();
+
+    for (int s = 0; s < p.nsteps; ++s) {
+        const uint64_t step = (uint64_t)(p.step0 + (uint32_t)s + 1u);
+        uint32_t uword = 0;
+
+        // ---- A: UpdateState, scalar half (TSimpleMCMC.H:1723-1776), one lane per chain ----
+        if (summer) {
+            ++trials;
+            const double x0 = x0s[lane];
+            const bool moved = (logl != last_value) || (x0 != last_x0);
+            if (moved) ++succ;
+            acc_rate *= acc_trials;
+            if (moved) acc_rate = acc_rate + 1.0;
+            acc_rate /= acc_trials + 1.0;
+            acc_trials = dmin(p.acc_window, acc_trials + 1.0);
+            if (rigid < 500.0 && rigid > 0.0) {
+                if (__builtin_fabs(acc_rate - p.target) < p.asig) {
+                    rigid += 0.5 * rigid / p.acc_window;
+                    rigid = dmin(200.0, rigid);
+                }
+                if (__builtin_fabs(acc_rate - p.target) > 4.0 * p.asig) {
+                    rigid -= 1.618 * 0.5 * rigid / p.acc_window;
+                    rigid = dmax(2.0, rigid);
+                }
+            }
+            if (rigid > 0 && rigid < 100.0) {
+                sigma *= smcmc_pow_small(acc_rate / p.target, dmin(1.0 / 500.0, 1.0 / (rigid * p.acc_window)));
+            }
+            if (p.per_lane_update && moved && (--next_update) < 1) {
+                double up = 0.5 * succ;
+                next_update = (int)(p.acc_window + p.max_up - p.max_up / (up + 1.0));
+                if (p.acc_w >= 0.0) {
+                    acc_trials = dmax(1.0, p.acc_w * acc_trials);
+                    acc_trials = dmin(acc_trials, p.acc_wW);
+                }
+            }
+            last_value = logl;
+            last_x0 = x0;
+            sig[lane] = sigma;
+            const uint32_t gid = p.chain_offset + (uint32_t)mychain;
+            const smcmc_u32x4 ablk = smcmc_draw_block(p.seed, gid, step, aw >> 2, SMCMC_STREAM_STEP);
+            uword = smcmc_select_word(ablk, aw & 3u);
+        }
+        __syncthreads();   // sigma published; the previous step's readers of qs are done
+
+        // ---- B1: z = sigma r (TSimpleMCMC.H:719-722): one Philox block = four rows of one chain ----
+        {
+            const int ntask = nkq * kPmCT;
+            for (int task = tid; task < ntask; task += kPmW * kWave) {
+                const int b = task / kPmCT, ch = task - b * kPmCT;
+                const uint32_t gid = p.chain_offset + (uint32_t)(base + ch);
+                const smcmc_u32x4 blk = smcmc_draw_block(p.seed, gid, step, (uint32_t)b, SMCMC_STREAM_STEP);
+                double n[4];
+                smcmc_normal_pair(blk.v[0], blk.v[1], &n[0], &n[1]);
+                smcmc_normal_pair(blk.v[2], blk.v[3], &n[2], &n[3]);
+                const double sg = sig[ch];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (4 * b + q < D) qs[(4 * b + q) * kPmCT + ch] = sg * n[q];
+            }
+        }
+        __syncthreads();
+
+        // ---- B2: x' = x + U^T z on the matrix pipe, rows i ascending ----
+        {
+            const double* uop = p.Uperm + lane;
+#pragma unroll
+            for (int t = 0; t < TI; ++t) {
+                xp[t][0] = x[t][0];
+                xp[t][1] = x[t][1];
+                if (!owns(t)) continue;
+                const int jt = tile(t);
+                const int kend = (4 * jt + 4 < nkq) ? 4 * jt + 4 : nkq;   // U(i, j) = 0 for i > j
+                const double* ut = uop + (size_t)jt * nkq * 64;
+                for (int kq = 0; kq < kend; ++kq) {
+                    const double a = ut[(size_t)kq * 64];
+                    const double b0 = qs[(4 * kq + rq) * kPmCT + c];
+                    const double b1 = qs[(4 * kq + rq) * kPmCT + 16 + c];
+                    xp[t][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0, xp[t][0], 0, 0, 0);
+                    xp[t][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b1, xp[t][1], 0, 0, 0);
+                }
+            }
+        }
+
+        // ---- StepRMS (TSimpleMCMC.H:391-406): sqr = fma(d, d, sqr), d = x' - x, dimension order ----
+        double sqr = 0.0;
+        if (p.step_rms_window > 0) {
+            publish([&](int t, int ct, int r) { return xp[t][ct][r] - x[t][ct][r]; });
+            if (summer)
+                for (int i = 0; i < D; ++i) {
+                    const double d = qs[i * kPmCT + lane];
+                    sqr = SMCMC_FMA(d, d, sqr);
+                }
+        }
+        // ---- likelihood of the proposal (:410), dimension order ----
+        publish([&](int t, int ct, int r) { return xp[t][ct][r]; });
+        if (summer) {
+            double lsum = 0.0;
+            if constexpr (LIKE == SMCMC_LIKE_ISO_GAUSS) {
+                for (int i = 0; i < D; ++i) {
+                    const double pi = qs[i * kPmCT + lane];
+                    lsum = SMCMC_FMA(-0.5 * pi, pi, lsum);
+                }
+            } else {
+                double prev = qs[lane];
+                for (int i = 0; i < D - 1; ++i) {
+                    const double nx = qs[(i + 1) * kPmCT + lane];
+                    const double a = 1.0 - prev;
+                    const double b = SMCMC_FMA(-prev, prev, nx);
+                    const double tt = SMCMC_FMA(rb * b, b, a * a);
+                    lsum -= tt;
+                    prev = nx;
+                }
+            }
+            if (p.step_rms_window > 0) {
+                double ms = step_rms * step_rms;
+                ms *= rms_trials;
+                ms += sqr;
+                ms /= rms_trials + 1.0;
+                rms_trials = (p.step_rms_window < rms_trials + 1) ? p.step_rms_window : rms_trials + 1;
+                step_rms = __builtin_sqrt(ms);
+            }
+            // ---- Metropolis test (:410-463) ----
+            logl_prop = lsum;
+            bool take;
+            if (p.metropolis == 2) {
+                take = true;
+            } else if (!__builtin_isfinite(logl_prop) || logl_prop < -0.999999E+30) {
+                take = false;
+            } else {
+                const double delta = logl_prop - logl;
+                take = true;
+                if (delta < 0.0) {
+                    if (p.metropolis == 1) take = false;
+                    else {
+                        const double trial = smcmc_log_pos(smcmc_u01(uword));
+                        if (delta < trial) take = false;
+                    }
+                }
+            }
+            take = take && active;
+            verdict[lane] = take ? 1 : 0;
+            last_accept = take ? 1 : 0;
+            if (take) {
+                ++naccept;
+                logl = logl_prop;
+                x0s[lane] = qs[lane];   // component 0 of the proposal
+            }
+        }
+        __syncthreads();
+        // ---- accept copy (:484-491) ----
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            const bool take = verdict[16 * ct + c] != 0;
+#pragma unroll
+            for (int t = 0; t < TI; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) x[t][ct][r] = take ? xp[t][ct][r] : x[t][ct][r];
+        }
+        if (p.save_x != nullptr && ((s + 1) % p.save_stride) == 0) {
+            const size_t sl = (size_t)((s + 1) / p.save_stride - 1);
+#pragma unroll
+            for (int t = 0; t < TI; ++t)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = comp(t, r), chain = base + 16 * ct + c;
+                        if (owns(t) && i < D && chain < p.nchains)
+                            p.save_x[(sl * (size_t)D + (size_t)i) * NP + chain] = x[t][ct][r];
+                    }
+            if (active) p.save_logl[sl * NP + mychain] = logl;
+        }
+    }
+
+#pragma unroll
+    for (int t = 0; t < TI; ++t)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = comp(t, r), chain = base + 16 * ct + c;
+                if (owns(t) && i < D && chain < p.nchains) p.x[(size_t)i * NP + chain] = x[t][ct][r];
+            }
+    if (active) {
+        double* lf = p.lane_f64 + mychain;
+        int32_t* li = p.lane_i32 + mychain;
+        lf[SMCMC_LANE_LOGL * NP] = logl;
+        lf[SMCMC_LANE_SIGMA * NP] = sigma;
+        lf[SMCMC_LANE_ACCEPTANCE * NP] = acc_rate;
+        lf[SMCMC_LANE_ACCEPTANCE_TRIALS * NP] = acc_trials;
+        lf[SMCMC_LANE_RIGIDITY * NP] = rigid;
+        lf[SMCMC_LANE_LAST_VALUE * NP] = last_value;
+        lf[SMCMC_LANE_LAST_X0 * NP] = last_x0;
+        lf[SMCMC_LANE_STEP_RMS * NP] = step_rms;
+        lf[SMCMC_LANE_LOGL_PROPOSED * NP] = logl_prop;
+        li[SMCMC_LANE_TRIALS * NP] = trials;
+        li[SMCMC_LANE_SUCCESSES * NP] = succ;
+        li[SMCMC_LANE_NEXT_UPDATE * NP] = next_update;
+        li[SMCMC_LANE_NACCEPT * NP] = naccept;
+        li[SMCMC_LANE_STEP_RMS_TRIALS * NP] = rms_trials;
+        li[SMCMC_LANE_LAST_ACCEPT * NP] = last_accept;
+    }
+}
+
+hipError_t launch_panel_mfma(const PanelParams& p, int like, hipStream_t stream);
+
+}  // namespace smcmc

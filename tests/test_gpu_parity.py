@@ -345,10 +345,12 @@ def test_frozen_large_dim_matches_oracle(gpu, oracle, kind, dim, nchains, steps,
 
 
 @pytest.mark.parametrize("dim,nchains,stride,window,nwin", [(100, 256, 1, 6, 3), (200, 192, 4, 8, 2), (300, 640, 3, 6, 2)])
-def test_pooled_large_dim_matches_oracle(gpu, oracle, dim, nchains, stride, window, nwin):
+@pytest.mark.parametrize("exact", [True, False])
+def test_pooled_large_dim_matches_oracle(gpu, oracle, dim, nchains, stride, window, nwin, exact):
     """Pooled covariance for D > 63: the moment fold runs as its own kernel (one wavefront
-    per 16x16 tile and chain slice) every `stride`-th step; still bit for bit the oracle."""
-    e, o = _pair(gpu, oracle, dim, nchains, 0, gpu.MODE_POOLED, True)
+    per 16x16 tile and chain slice) every `stride`-th step; still bit for bit the oracle.  In the
+    fused order the proposal runs on the matrix pipe (smcmc_panel_mfma_kernel.hip.h)."""
+    e, o = _pair(gpu, oracle, dim, nchains, 0, gpu.MODE_POOLED, exact)
     e.set_param("MOMENT_STRIDE", stride)
     o.set_moment_grouping(int(e.get_param("MOMENT_GROUP")), stride)
     assert e.Start(np.zeros(dim)) and o.start(np.zeros(dim))

@@ -18,7 +18,8 @@
 
 namespace smcmc {
 
-constexpr int kFoldSlices = 4;   // chain slices (moment groups) of the large-dimension path
+constexpr int kFoldSlices = 32;   // chain slices (moment groups) of the large-dimension path
+constexpr int kFoldBT = 4;        // a wavefront folds a block of kFoldBT x kFoldBT tiles (64 x 64 moments)
 
 // row r of the augmented point y: dims 0..D-1, the constant 1 at r == D, zero above
 __device__ __forceinline__ double fold_operand(const double* __restrict__ x, size_t NP, int D, int r, int chain,
@@ -28,37 +29,65 @@ __device__ __forceinline__ double fold_operand(const double* __restrict__ x, siz
     return (r == D) ? 1.0 : 0.0;
 }
 
-// grid = (ntiles, kFoldSlices), block = 64.  tile -> (ti, tj <= ti).
+// grid = (nblocks, kFoldSlices), block = 64.  block -> (bi, bj <= bi) of 4 x 4 tiles: eight operand
+// reads feed sixteen matrix instructions (a quarter of the state traffic of one tile per wavefront).
 static __global__ void __launch_bounds__(kWave) fold_moments_kernel(const double* __restrict__ x, const double* __restrict__ c0,
                                                              int nchains, int npad, int D, int slice_chains,
                                                              double* __restrict__ gacc) {
     const int lane = threadIdx.x;
-    const int tile = blockIdx.x, slice = blockIdx.y;
-    int ti = 0;
-    while ((ti + 1) * (ti + 2) / 2 <= tile) ++ti;
-    const int tj = tile - ti * (ti + 1) / 2;
-    const int ra = 16 * ti + (lane & 15), rb = 16 * tj + (lane & 15);
-    const double ca = (ra < D) ? c0[ra] : 0.0, cb = (rb < D) ? c0[rb] : 0.0;
+    const int slice = blockIdx.y;
+    const int T = (D + 1 + 15) / 16, ntiles = T * (T + 1) / 2;
+    int bi = 0;
+    while ((bi + 1) * (bi + 2) / 2 <= (int)blockIdx.x) ++bi;
+    const int bj = (int)blockIdx.x - bi * (bi + 1) / 2;
     const size_t NP = (size_t)npad;
-    const size_t off = (((size_t)slice * gridDim.x + tile) * 4) * kWave + lane;
-    f64x4 acc;
+    int ra[kFoldBT], rb[kFoldBT];
+    double ca[kFoldBT], cb[kFoldBT];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) acc[r] = gacc[off + (size_t)r * kWave];
+    for (int a = 0; a < kFoldBT; ++a) {
+        ra[a] = 16 * (kFoldBT * bi + a) + (lane & 15);
+        rb[a] = 16 * (kFoldBT * bj + a) + (lane & 15);
+        ca[a] = (ra[a] < D) ? c0[ra[a]] : 0.0;
+        cb[a] = (rb[a] < D) ? c0[rb[a]] : 0.0;
+    }
+    // tile (ti, tj) of the block: valid when it exists and lies in the lower triangle
+    auto valid = [&](int a, int b) { return kFoldBT * bi + a < T && kFoldBT * bj + b <= kFoldBT * bi + a; };
+    auto offset = [&](int a, int b) {
+        const int ti = kFoldBT * bi + a, tj = kFoldBT * bj + b;
+        return (((size_t)slice * ntiles + (size_t)(ti * (ti + 1) / 2 + tj)) * 4) * kWave + lane;
+    };
+    f64x4 acc[kFoldBT][kFoldBT];
+#pragma unroll
+    for (int a = 0; a < kFoldBT; ++a)
+#pragma unroll
+        for (int b = 0; b < kFoldBT; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[a][b][r] = valid(a, b) ? gacc[offset(a, b) + (size_t)r * kWave] : 0.0;
     const int c_begin = slice * slice_chains;
     const int c_end = (c_begin + slice_chains < npad) ? c_begin + slice_chains : npad;
-    for (int c = c_begin; c < c_end; c += 16) {
-        double a[4], b[4];
+#pragma unroll 8
+    for (int c = c_begin; c < c_end; c += 4) {
+        const int chain = c + (lane >> 4);
+        double av[kFoldBT], bv[kFoldBT];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int chain = c + 4 * k + (lane >> 4);
-            a[k] = fold_operand(x, NP, D, ra, chain, (chain < c_end) ? nchains : 0, ca);
-            b[k] = fold_operand(x, NP, D, rb, chain, (chain < c_end) ? nchains : 0, cb);
+        for (int a = 0; a < kFoldBT; ++a) {
+            av[a] = fold_operand(x, NP, D, ra[a], chain, nchains, ca[a]);
+            bv[a] = fold_operand(x, NP, D, rb[a], chain, nchains, cb[a]);
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[k], b[k], acc, 0, 0, 0);
+        for (int a = 0; a < kFoldBT; ++a)
+#pragma unroll
+            for (int b = 0; b < kFoldBT; ++b)
+                if (valid(a, b)) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], acc[a][b], 0, 0, 0);
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) gacc[off + (size_t)r * kWave] = acc[r];
+    for (int a = 0; a < kFoldBT; ++a)
+#pragma unroll
+        for (int b = 0; b < kFoldBT; ++b)
+            if (valid(a, b)) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gacc[offset(a, b) + (size_t)r * kWave] = acc[a][b][r];
+            }
 }
 
 // packed element k = (i, j), j <= i <= D  ->  sum over slices (ascending) of its tile entry

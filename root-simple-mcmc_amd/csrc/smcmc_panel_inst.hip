@@ -33,8 +33,8 @@ hipError_t launch_panel<SMCMC_PANEL_W, kPanelCW>(const PanelParams& p, int like,
 #if SMCMC_PANEL_W == 4
 hipError_t launch_fold(const double* x, const double* c0, int nchains, int npad, int D, int slice_chains,
                        double* gacc, hipStream_t s) {
-    const int T = (D + 1 + 15) / 16, ntiles = T * (T + 1) / 2;
-    hipLaunchKernelGGL(fold_moments_kernel, dim3(ntiles, kFoldSlices), dim3(kWave), 0, s, x, c0, nchains, npad, D,
+    const int T = (D + 1 + 15) / 16, TB = (T + kFoldBT - 1) / kFoldBT, nblocks = TB * (TB + 1) / 2;
+    hipLaunchKernelGGL(fold_moments_kernel, dim3(nblocks, kFoldSlices), dim3(kWave), 0, s, x, c0, nchains, npad, D,
                        slice_chains, gacc);
     return hipGetLastError();
 }

@@ -48,6 +48,42 @@ def pooled(dim, kind, nchains, window, nwin):
             "decomposition": e.decomposition}
 
 
+def frozen_ensemble(dim, kind, nchains, steps, exact, x0):
+    """Large dimensions: end state of a FROZEN ensemble in the reference or the fused order."""
+    prm = [100.0] if kind == O.LIKE_ROSENBROCK else None
+    e = O.Ensemble(nchains, dim, kind=kind, params=prm, seed=SEED, mode=O.MODE_FROZEN, exact=exact)
+    assert e.start(x0)
+    e.step(steps)
+    return {"dim": dim, "kind": kind, "nchains": nchains, "steps": steps, "exact": int(exact), "seed": SEED, "x0": x0,
+            "x": e.x, "logl": e.lane("logl"), "sigma": e.lane("sigma"), "naccept": e.lane("naccept"),
+            "step_rms": e.lane("step_rms")}
+
+
+def spd(dim, seed):
+    rng = np.random.default_rng(seed)
+    a = rng.standard_normal((dim, dim)) / np.sqrt(dim)
+    return a @ a.T + np.eye(dim)
+
+
+def hmc_chains(dim, nchains, steps, leap, eps, alpha, fused):
+    """TSimpleHMC with the quadratic-form likelihood, fixed step and leapfrog count."""
+    err = spd(dim, dim)
+    q, m, pot, acc = [], [], [], []
+    for ch in range(nchains):
+        h = O.Hmc(dim, kind=O.LIKE_QUADFORM, params=err, seed=SEED, chain_id=ch, potential_from_gradient=True,
+                  fused_gradient=fused)
+        h.set_alpha(alpha)
+        h.start(np.ones(dim))
+        h.set_mean_epsilon(-eps)
+        h.set_leapfrog(leap)
+        h.run(steps)
+        q.append(h.accepted); m.append(h.momentum); pot.append(h.scalars["accepted_potential"])
+        acc.append(h.scalars["current_acceptance"])
+    return {"dim": dim, "nchains": nchains, "steps": steps, "leapfrog": leap, "epsilon": eps, "alpha": alpha,
+            "fused": int(fused), "seed": SEED, "error": err, "q": np.array(q).T, "momentum": np.array(m).T,
+            "potential": np.array(pot), "acceptance": np.array(acc)}
+
+
 def main():
     O.build()
     np.savez(os.path.join(HERE, "frozen_iso_d5.npz"), **frozen_chains(5, O.LIKE_ISO, 4, 300, np.zeros(5)))
@@ -57,6 +93,14 @@ def main():
     np.savez(os.path.join(HERE, "frozen_iso_d50.npz"), **frozen_chains(50, O.LIKE_ISO, 3, 60, np.zeros(50)))
     np.savez(os.path.join(HERE, "pooled_iso_d5.npz"), **pooled(5, O.LIKE_ISO, 70, 16, 3))
     np.savez(os.path.join(HERE, "pooled_iso_d20.npz"), **pooled(20, O.LIKE_ISO, 130, 8, 3))
+    for exact in (True, False):
+        tag = "reference" if exact else "fused"
+        np.savez(os.path.join(HERE, f"frozen_iso_d200_{tag}.npz"),
+                 **frozen_ensemble(200, O.LIKE_ISO, 40, 12, exact, np.zeros(200)))
+        np.savez(os.path.join(HERE, f"frozen_rosenbrock_d100_{tag}.npz"),
+                 **frozen_ensemble(100, O.LIKE_ROSENBROCK, 40, 12, exact, rng.uniform(0.5, 1.5, (100, 40))))
+    np.savez(os.path.join(HERE, "hmc_quadform_d60_reference.npz"), **hmc_chains(60, 6, 6, 8, 0.05, 0.3, False))
+    np.savez(os.path.join(HERE, "hmc_quadform_d60_fused.npz"), **hmc_chains(60, 6, 6, 8, 0.05, 0.3, True))
 
 
 if __name__ == "__main__":

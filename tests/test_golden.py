@@ -9,6 +9,9 @@ import pytest
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 FROZEN = ["frozen_iso_d5.npz", "frozen_rosenbrock_d6.npz", "frozen_iso_d50.npz"]
 POOLED = ["pooled_iso_d5.npz", "pooled_iso_d20.npz"]
+LARGE = ["frozen_iso_d200_reference.npz", "frozen_iso_d200_fused.npz", "frozen_rosenbrock_d100_reference.npz",
+         "frozen_rosenbrock_d100_fused.npz"]
+HMC = ["hmc_quadform_d60_reference.npz", "hmc_quadform_d60_fused.npz"]
 
 
 def _load(name):
@@ -86,3 +89,70 @@ def test_hip_reproduces_pooled_golden(gpu, name):
     assert np.array_equal(e.lane("naccept"), g["naccept"])
     assert np.array_equal(e.decomposition, g["decomposition"]) and np.array_equal(e.covariance, g["covariance"])
     assert np.array_equal(e.GetEstimatedCenter(), g["center"])
+
+
+# ---------------------------------------------------------------- large dimensions and HMC
+@pytest.mark.parametrize("name", LARGE)
+def test_oracle_reproduces_large_dim_golden(oracle, name):
+    g = _load(name)
+    dim, kind, n = int(g["dim"]), int(g["kind"]), int(g["nchains"])
+    prm = [100.0] if kind == 2 else None
+    e = oracle.Ensemble(n, dim, kind=kind, params=prm, seed=int(g["seed"]), mode=oracle.MODE_FROZEN,
+                        exact=bool(g["exact"]))
+    assert e.start(g["x0"])
+    e.step(int(g["steps"]))
+    assert np.array_equal(e.x, g["x"]) and np.array_equal(e.lane("logl"), g["logl"])
+    assert np.array_equal(e.lane("sigma"), g["sigma"]) and np.array_equal(e.lane("naccept"), g["naccept"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", LARGE)
+def test_hip_reproduces_large_dim_golden(gpu, name):
+    """D > 63: the panel kernel (reference order) and the matrix-pipe kernel (fused order)."""
+    g = _load(name)
+    dim, kind, n = int(g["dim"]), int(g["kind"]), int(g["nchains"])
+    prm = [100.0] if kind == 2 else None
+    e = gpu.Engine(dim, n, likelihood=kind, likelihood_params=prm, seed=int(g["seed"]), mode=gpu.MODE_FROZEN,
+                   exact=bool(g["exact"]))
+    assert e.Start(g["x0"])
+    e.Step(int(g["steps"]))
+    assert np.array_equal(e.GetAccepted(), g["x"]) and np.array_equal(e.lane("logl"), g["logl"])
+    assert np.array_equal(e.lane("sigma"), g["sigma"]) and np.array_equal(e.lane("naccept"), g["naccept"])
+    assert np.array_equal(e.lane("step_rms"), g["step_rms"])
+
+
+def _hmc_oracle_state(oracle, g):
+    dim, n = int(g["dim"]), int(g["nchains"])
+    q, m, pot = [], [], []
+    for ch in range(n):
+        h = oracle.Hmc(dim, kind=1, params=g["error"], seed=int(g["seed"]), chain_id=ch, potential_from_gradient=True,
+                       fused_gradient=bool(g["fused"]))
+        h.set_alpha(float(g["alpha"])); h.start(np.ones(dim))
+        h.set_mean_epsilon(-float(g["epsilon"])); h.set_leapfrog(int(g["leapfrog"]))
+        h.run(int(g["steps"]))
+        q.append(h.accepted); m.append(h.momentum); pot.append(h.scalars["accepted_potential"])
+    return np.array(q).T, np.array(m).T, np.array(pot)
+
+
+@pytest.mark.parametrize("name", HMC)
+def test_oracle_reproduces_hmc_golden(oracle, name):
+    g = _load(name)
+    q, m, pot = _hmc_oracle_state(oracle, g)
+    assert np.array_equal(q, g["q"]) and np.array_equal(m, g["momentum"]) and np.array_equal(pot, g["potential"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", HMC)
+def test_hip_reproduces_hmc_golden(gpu, name):
+    g = _load(name)
+    dim, n = int(g["dim"]), int(g["nchains"])
+    e = gpu.HmcEngine(dim, n, likelihood=1, likelihood_params=g["error"], seed=int(g["seed"]),
+                      exact=not bool(g["fused"]))
+    e.SetAlpha(float(g["alpha"]))
+    e.Start(np.ones(dim))
+    e.SetMeanEpsilon(-float(g["epsilon"]))
+    e.SetLeapFrog(int(g["leapfrog"]))
+    e.Step(int(g["steps"]))
+    q, m, logl = e.state()
+    assert np.array_equal(q, g["q"]) and np.array_equal(m, g["momentum"]) and np.array_equal(-logl, g["potential"])
+    assert np.array_equal(e.lane("acceptance"), g["acceptance"])

@@ -48,7 +48,7 @@ dt = timed(lambda: e.Step(32), 3)
 out["config4_iso_d500_32768_frozen_fused_matrix_pipe"] = {
     "chain_steps_per_s": 32768 * 32 / dt, "ms_per_step": dt / 32 * 1e3,
     "proposal_TFLOPs": 32768 * 32 / dt * 500 * 501 / 1e12}
-# configs 3 and 4 with the pooled covariance: moment fold every 16th step, sync every 64 steps
+# configs 3 and 4 with the pooled covariance: moment fold every 16th step, sync every 256 steps (BASELINE config 4)
 for name, dim, n, kind, prm in (("config3_rosenbrock_d200_16384_pooled", 200, 16384, pkg.LIKE_ROSENBROCK, [100.0]),
                                ("config4_iso_d500_32768_pooled", 500, 32768, pkg.LIKE_ISO_GAUSS, None)):
     for exact in (True, False):
@@ -57,11 +57,11 @@ for name, dim, n, kind, prm in (("config3_rosenbrock_d200_16384_pooled", 200, 16
         e.Start(rng.uniform(0.5, 1.5, (dim, n)) if kind == pkg.LIKE_ROSENBROCK else np.zeros(dim))
 
         def window():
-            e.Step(64)
+            e.Step(256)
             e.sync()
-        dt = timed(window, 2)
+        dt = timed(window, 1)
         out[name + ("" if exact else "_fused_matrix_pipe")] = {
-            "chain_steps_per_s": n * 64 / dt, "ms_per_step": dt / 64 * 1e3,
+            "chain_steps_per_s": n * 256 / dt, "ms_per_step": dt / 256 * 1e3,
             "accept": float(e.lane("naccept").sum() / (e.get_param("TOTAL_STEPS") * n))}
 # config 5: HMC, header TDummy D=500 (Error from Init()), 8 192 chains x 20 leapfrog steps
 from oracle import oracle as O  # noqa: E402  (only for TDummyLogLikelihood::Init's Error matrix)

@@ -77,3 +77,46 @@ def test_example_continues_a_chain_from_its_output(gpu, tmp_path):
     assert int(a["TotalSteps"]) == (1 + 4 + 2) * 1000
     assert int(b["TotalSteps"]) == int(a["TotalSteps"]) + (1 + 4 + 1) * 500      # the step count carries over
     assert abs(float(b["AdaptiveCovarianceTrace"]) / 5.0 - 1.0) < 0.25
+
+
+def _build_hmc(tmp_path):
+    exe = str(tmp_path / "hmc_amd.exe")
+    cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-Werror", f"-I{os.path.join(ROOT, 'include')}",
+           os.path.join(ROOT, "examples", "SimpleHMC_amd.C"), f"-L{LIBDIR}", "-lsmcmc_amd",
+           f"-Wl,-rpath,{LIBDIR}", "-Wl,-rpath,/opt/rocm/lib", "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return exe
+
+
+def test_hmc_example_compiles(smcmc, tmp_path):
+    _build_hmc(tmp_path)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fused", [0, 1])
+def test_hmc_example_runs(gpu, tmp_path, fused):
+    """SimpleHMC.C on the engine (TSimpleHMC_amd.H): schema of TSimpleHMC.H:139-147, the gradient count of
+    21 per step, a posterior of the right scale."""
+    exe = _build_hmc(tmp_path)
+    out = tmp_path / "hmc.csv"
+    dim, trials = 20, 400
+    r = subprocess.run([exe, str(trials), str(out), str(dim), "96", str(fused)], capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = open(out).read().splitlines()
+    header = lines[0].split(",")
+    names = {h.split("[")[0] for h in header if h}
+    assert names >= {"LogLikelihood", "Accepted", "Trace", "LikelihoodCalls", "Steps", "Acceptance", "MeanEpsilon",
+                     "Orbit", "Leapfrog"}
+    col = {h: i for i, h in enumerate(header) if h}
+    rows = [l.split(",") for l in lines[1:]]
+    assert len(rows) == trials + 1                                   # Start(p, true) + one entry per saved step
+    assert int(rows[-1][col["Steps"]]) == 100 + dim + trials
+    assert f"{(100 + dim + trials) * 21} gradients" in r.stdout
+    acc = float(rows[-1][col["Acceptance"]])
+    assert 0.65 < acc <= 1.0                                          # started at 0.65 (:234), mostly accepting
+    x1 = np.array([float(r_[col["Accepted[1]"]]) for r_ in rows])
+    logl = np.array([float(r_[col["LogLikelihood"]]) for r_ in rows])
+    assert len(np.unique(x1)) > trials // 2 and np.all(np.isfinite(logl))   # the chain moves
+    assert logl[-1] < logl[0]                                         # potential falls from U(p = 1) toward equilibrium

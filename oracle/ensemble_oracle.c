@@ -35,6 +35,7 @@ typedef struct {
     uint32_t chain_offset;
     int mode;
     int exact;                 /* 1: reference operation order, 0: fused multiply-add order */
+    int quadform_rowwise;      /* fused order at D > 63: log L = -sum_i 0.5 p_i (sum_j fma(E(i,j), p_j, .)) */
     oracle_proposal prop;      /* shared proposal: U, cov, centre, windows, target ... */
     int total_steps;
     /* per chain, [d][chain] for vectors */
@@ -129,6 +130,7 @@ void oracle_ensemble_set_moment_grouping(oracle_ensemble* e, int group_chains, i
 }
 
 /* shared-proposal setters (before start) */
+void oracle_ensemble_set_quadform_rowwise(oracle_ensemble* e, int f) { e->quadform_rowwise = f; }
 void oracle_ensemble_set_gaussian(oracle_ensemble* e, int d, double sigma) { e->prop.ptype[d] = 0; e->prop.pparam1[d] = sigma * sigma; }
 void oracle_ensemble_set_uniform(oracle_ensemble* e, int d, double lo, double hi) { e->prop.ptype[d] = 1; e->prop.pparam1[d] = lo; e->prop.pparam2[d] = hi; }
 void oracle_ensemble_set_correlation(oracle_ensemble* e, int d1, int d2, double c) { oracle_proposal_set_correlation(&e->prop, d1, d2, c); }
@@ -157,6 +159,17 @@ static double ens_like(const oracle_ensemble* e, const double* p) {
             for (int i = 0; i < n; ++i) logl = SMCMC_FMA(-0.5 * p[i], p[i], logl);
             return logl;
         case ORACLE_LIKE_QUADFORM:
+            if (e->quadform_rowwise) {
+                /* the matrix-pipe kernel's association (smcmc_panel_mfma_kernel.hip.h): row sums of
+                 * Error p by fused multiply-adds, j ascending, then the outer sum in dimension order */
+                double usum = 0.0;
+                for (int i = 0; i < n; ++i) {
+                    double s = 0.0;
+                    for (int j = 0; j < n; ++j) s = SMCMC_FMA(e->like_params[i * n + j], p[j], s);
+                    usum += 0.5 * p[i] * s;
+                }
+                return -usum;
+            }
             for (int i = 0; i < n; ++i) {
                 double h = 0.5 * p[i];
                 for (int j = 0; j < n; ++j) logl = SMCMC_FMA(-(h * e->like_params[j * n + i]), p[j], logl);

@@ -107,7 +107,7 @@ def _declare(L):
         ("set_covariance_deweight", [C.c_double]), ("set_acceptance_window", [C.c_double]),
         ("set_acceptance_deweight", [C.c_double]), ("set_acceptance_rigidity", [C.c_double]),
         ("set_target_acceptance", [C.c_double]), ("set_step_rms_window", [C.c_int]),
-        ("set_sigma", [C.c_double]), ("set_moment_grouping", [C.c_int, C.c_int]),
+        ("set_sigma", [C.c_double]), ("set_moment_grouping", [C.c_int, C.c_int]), ("set_quadform_rowwise", [C.c_int]),
         ("step", [C.c_int, C.c_int]), ("reduce_moments", [_dp]),
         ("apply_moments", [_dp]), ("sync", []), ("get_x", [_dp]), ("get_lane_f64", [C.c_int, _dp]),
         ("get_lane_i32", [C.c_int, _ip]), ("get_last_accept", [_bp]), ("get_center", [_dp]),

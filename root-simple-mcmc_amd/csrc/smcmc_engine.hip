@@ -201,9 +201,27 @@ int upload_like(smcmc_engine* h) {
     if (h->likelihood == SMCMC_LIKE_QUADFORM) {
         if ((int)h->like_params.size() != h->dim * h->dim)
             return fail(h, SMCMC_ERR_INVALID, "QUADFORM needs dim*dim likelihood parameters (the Error matrix)");
+        const int D = h->dim;
+        if (h->panel_w) {
+            // large dimensions: Error in matrix-operand order for the row sums of panel_mfma_kernel
+            if (h->exact)
+                return fail(h, SMCMC_ERR_UNSUPPORTED,
+                            "the quadratic-form likelihood for dim > 63 runs in the fused order only "
+                            "(SMCMC_P_EXACT_ARITHMETIC = 0): its reference order is one serial D^2-term sum per chain");
+            const int ntiles = (D + 15) / 16, nkq = (D + 3) / 4;
+            std::vector<double> eop(panel_mfma_uop_doubles(D), 0.0);
+            for (int it = 0; it < ntiles; ++it)
+                for (int kq = 0; kq < nkq; ++kq)
+                    for (int l = 0; l < 64; ++l) {
+                        const int i = 16 * it + (l & 15), j = 4 * kq + (l >> 4);
+                        if (i < D && j < D) eop[((size_t)it * nkq + kq) * 64 + l] = h->like_params[(size_t)i * D + j];
+                    }
+            HIP_TRY(h, hipMemcpyAsync(h->d_like, eop.data(), eop.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+            return SMCMC_OK;
+        }
         // the kernel walks Error(j,i) with j innermost (TDummyLogLikelihood.H:24-28): hand it
         // the transpose so that walk is contiguous
-        const int D = h->dim;
         std::vector<double> et((size_t)D * D);
         for (int i = 0; i < D; ++i)
             for (int j = 0; j < D; ++j) et[(size_t)i * D + j] = h->like_params[(size_t)j * D + i];
@@ -290,6 +308,8 @@ int launch(smcmc_engine* h, int nsteps, int metropolis, int stride, double* save
         q.x = p.x; q.lane_f64 = p.lane_f64; q.lane_i32 = p.lane_i32;
         q.save_stride = 1;
         const bool exact = h->exact || h->prop->decompFull;
+        if (exact && h->likelihood == SMCMC_LIKE_QUADFORM)
+            return fail(h, SMCMC_ERR_UNSUPPORTED, "the quadratic-form likelihood for dim > 63 runs in the fused order only");
         const bool pooled = (h->mode == SMCMC_MODE_POOLED);
         if (pooled && save_x) return fail(h, SMCMC_ERR_UNSUPPORTED, "saving inside a pooled large-dimension launch");
         if (!pooled) { q.save_x = p.save_x; q.save_logl = p.save_logl; q.save_stride = p.save_stride; }
@@ -384,8 +404,7 @@ int smcmc_create(int dim, int nchains, int likelihood, uint64_t seed, uint32_t c
         if (dim <= 4 * kPanelCW) panel_w = 4;
         else if (dim <= 8 * kPanelCW) panel_w = 8;
         else return SMCMC_ERR_UNSUPPORTED;
-        if (likelihood == SMCMC_LIKE_QUADFORM) return SMCMC_ERR_UNSUPPORTED;
-        dp = dim;
+        dp = dim;   // QUADFORM here runs in the fused order only (checked at Start)
     }
     smcmc_engine* h = new (std::nothrow) smcmc_engine();
     if (!h) return SMCMC_ERR_RUNTIME;
@@ -410,7 +429,8 @@ int smcmc_create(int dim, int nchains, int likelihood, uint64_t seed, uint32_t c
         HIP_TRY(h, hipMalloc(&h->d_Uop, sizeof(double) * panel_mfma_uop_doubles(dim)));
         HIP_TRY(h, hipMemset(h->d_Uop, 0, sizeof(double) * panel_mfma_uop_doubles(dim)));
     }
-    HIP_TRY(h, hipMalloc(&h->d_like, sizeof(double) * dp * dp));
+    const size_t like_doubles = std::max((size_t)dp * dp, panel_w ? panel_mfma_uop_doubles(dim) : (size_t)0);
+    HIP_TRY(h, hipMalloc(&h->d_like, sizeof(double) * like_doubles));
     HIP_TRY(h, hipMalloc(&h->d_c0, sizeof(double) * dp));
     HIP_TRY(h, hipMalloc(&h->d_gacc, sizeof(double) * gacc_doubles(h)));
     HIP_TRY(h, hipMalloc(&h->d_moments, sizeof(double) * npacked(h)));
@@ -421,7 +441,7 @@ int smcmc_create(int dim, int nchains, int likelihood, uint64_t seed, uint32_t c
     HIP_TRY(h, hipMemset(h->d_uniform, 0, sizeof(double) * 2 * dp));
     HIP_TRY(h, hipMemset(h->d_lane_f64, 0, sizeof(double) * np * SMCMC_LANE_F64_COUNT_));
     HIP_TRY(h, hipMemset(h->d_lane_i32, 0, sizeof(int32_t) * np * SMCMC_LANE_I32_COUNT_));
-    HIP_TRY(h, hipMemset(h->d_like, 0, sizeof(double) * dp * dp));
+    HIP_TRY(h, hipMemset(h->d_like, 0, sizeof(double) * like_doubles));
     HIP_TRY(h, hipMemset(h->d_c0, 0, sizeof(double) * dp));
     HIP_TRY(h, hipMemset(h->d_gacc, 0, sizeof(double) * gacc_doubles(h)));
     HIP_TRY(h, hipMemset(h->d_moments, 0, sizeof(double) * npacked(h)));
@@ -616,7 +636,15 @@ static int place_chains(smcmc_engine* h, const double* x0, int broadcast, std::v
     HIP_TRY(h, hipMemsetAsync(h->d_lane_f64, 0, sizeof(double) * NP * SMCMC_LANE_F64_COUNT_, h->stream));
     HIP_TRY(h, hipMemsetAsync(h->d_lane_i32, 0, sizeof(int32_t) * NP * SMCMC_LANE_I32_COUNT_, h->stream));
     HIP_TRY(h, hipMemsetAsync(h->d_gacc, 0, sizeof(double) * gacc_doubles(h), h->stream));
-    if (h->panel_w) {
+    if (h->panel_w && h->likelihood == SMCMC_LIKE_QUADFORM) {
+        PanelParams q;
+        std::memset(&q, 0, sizeof(q));
+        q.nchains = N; q.npad = h->npad; q.dim = D; q.init_only = 1;
+        q.like = h->d_like; q.x = h->d_x; q.lane_f64 = h->d_lane_f64; q.lane_i32 = h->d_lane_i32;
+        q.pending_sigma_scale = 1.0; q.save_stride = 1;
+        hipError_t e = launch_panel_mfma(q, h->likelihood, h->stream);
+        if (e != hipSuccess) return fail(h, SMCMC_ERR_HIP, std::string("start kernel launch: ") + hipGetErrorString(e));
+    } else if (h->panel_w) {
         hipError_t e = launch_start_loglike(h->d_x, N, NP, D, h->d_like, h->d_lane_f64 + (size_t)SMCMC_LANE_LOGL * NP,
                                             h->likelihood, h->exact, h->stream);
         if (e != hipSuccess) return fail(h, SMCMC_ERR_HIP, std::string("start kernel launch: ") + hipGetErrorString(e));

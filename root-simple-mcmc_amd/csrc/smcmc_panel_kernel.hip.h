@@ -50,6 +50,7 @@ struct PanelParams {
     double* save_x;           // optional [slot][dim][npad]
     double* save_logl;
     int save_stride;
+    int init_only;            // matrix-pipe kernel: only evaluate log L at x into LANE_LOGL (Start, :258)
 };
 
 template <int W, int CW, int LIKE, bool EXACT>

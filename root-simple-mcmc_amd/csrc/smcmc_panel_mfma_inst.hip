@@ -15,6 +15,7 @@ static hipError_t go_panel_mfma(const PanelParams& p, hipStream_t s) {
 hipError_t launch_panel_mfma(const PanelParams& p, int like, hipStream_t s) {
     switch (like) {
         case SMCMC_LIKE_ISO_GAUSS: return go_panel_mfma<SMCMC_LIKE_ISO_GAUSS>(p, s);
+        case SMCMC_LIKE_QUADFORM: return go_panel_mfma<SMCMC_LIKE_QUADFORM>(p, s);
         case SMCMC_LIKE_ROSENBROCK: return go_panel_mfma<SMCMC_LIKE_ROSENBROCK>(p, s);
         default: return hipErrorInvalidValue;
     }

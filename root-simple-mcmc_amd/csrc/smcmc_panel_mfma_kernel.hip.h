@@ -17,6 +17,13 @@
 // likelihood, which sum over all components in index order, are walked by one lane per chain over
 // values published through the same LDS array; those lanes also carry the per-chain scalar state
 // (UpdateState's scalar half, TSimpleMCMC.H:1723-1776) and run the Metropolis test (:410-463).
+//
+// LIKE = QUADFORM (TDummyLogLikelihood.H:21-31 at D > 63): log L = -1/2 sum_i p_i (Error p)_i, the rows
+// (Error p)_i = sum_j fma(Error(i,j), p_j, .) by a second chain of matrix instructions (Eop in the
+// `like` pointer, the layout of hmc_mfma_kernel), the outer sum in dimension order -- the association
+// oracle/ensemble_oracle.c calls quadform_rowwise.  To make room for the row sums the accepted point
+// is not held in registers across the likelihood: p.x in HBM is kept current (written on accept) and
+// read back after the verdict.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -124,6 +131,49 @@ __global__ void __launch_bounds__(kPmW* kWave, 1) panel_mfma_kernel(const PanelP
     for (int k = tid; k < 16 * kPmW * TI * kPmCT; k += kPmW * kWave) qs[k] = 0.0;
     __syncthreads();
 
+    // QUADFORM: v <- 0.5 v (Error v) element by element, v published in qs; the caller sums it in order
+    auto quadform_terms = [&](f64x4v (&v)[TI][2]) {
+        f64x4v gr[TI][2];
+#pragma unroll
+        for (int t = 0; t < TI; ++t) {
+            gr[t][0] = f64x4v{0.0, 0.0, 0.0, 0.0};
+            gr[t][1] = f64x4v{0.0, 0.0, 0.0, 0.0};
+        }
+        const double* eop = p.like + lane;
+        for (int kq = 0; kq < nkq; ++kq) {
+            const double b0 = qs[(4 * kq + rq) * kPmCT + c];
+            const double b1 = qs[(4 * kq + rq) * kPmCT + 16 + c];
+#pragma unroll
+            for (int t = 0; t < TI; ++t) {
+                if (!owns(t)) continue;
+                const double a = eop[((size_t)tile(t) * nkq + kq) * 64];
+                gr[t][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0, gr[t][0], 0, 0, 0);
+                gr[t][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b1, gr[t][1], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < TI; ++t)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gr[t][ct][r] = 0.5 * v[t][ct][r] * gr[t][ct][r];
+        publish([&](int t, int ct, int r) { return gr[t][ct][r]; });
+    };
+
+    if (p.init_only) {
+        // Start's likelihood call (TSimpleMCMC.H:258) in this kernel's association
+        if constexpr (LIKE == SMCMC_LIKE_QUADFORM) {
+            publish([&](int t, int ct, int r) { return x[t][ct][r]; });
+            quadform_terms(x);
+            if (summer) {
+                double usum = 0.0;
+                for (int i = 0; i < D; ++i) usum += qs[i * kPmCT + lane];
+                if (active) p.lane_f64[SMCMC_LANE_LOGL * NP + mychain] = -usum;
+            }
+        }
+        return;
+    }
+
     for (int s = 0; s < p.nsteps; ++s) {
         const uint64_t step = (uint64_t)(p.step0 + (uint32_t)s + 1u);
         uint32_t uword = 0;
@@ -219,9 +269,16 @@ __global__ void __launch_bounds__(kPmW* kWave, 1) panel_mfma_kernel(const PanelP
         }
         // ---- likelihood of the proposal (:410), dimension order ----
         publish([&](int t, int ct, int r) { return xp[t][ct][r]; });
+        double prop0 = 0.0;
+        if (summer) prop0 = qs[lane];   // component 0 of the proposal
+        if constexpr (LIKE == SMCMC_LIKE_QUADFORM) quadform_terms(xp);
         if (summer) {
             double lsum = 0.0;
-            if constexpr (LIKE == SMCMC_LIKE_ISO_GAUSS) {
+            if constexpr (LIKE == SMCMC_LIKE_QUADFORM) {
+                double usum = 0.0;
+                for (int i = 0; i < D; ++i) usum += qs[i * kPmCT + lane];
+                lsum = -usum;
+            } else if constexpr (LIKE == SMCMC_LIKE_ISO_GAUSS) {
                 for (int i = 0; i < D; ++i) {
                     const double pi = qs[i * kPmCT + lane];
                     lsum = SMCMC_FMA(-0.5 * pi, pi, lsum);
@@ -269,7 +326,7 @@ __global__ void __launch_bounds__(kPmW* kWave, 1) panel_mfma_kernel(const PanelP
             if (take) {
                 ++naccept;
                 logl = logl_prop;
-                x0s[lane] = qs[lane];   // component 0 of the proposal
+                x0s[lane] = prop0;
             }
         }
         __syncthreads();
@@ -277,10 +334,25 @@ __global__ void __launch_bounds__(kPmW* kWave, 1) panel_mfma_kernel(const PanelP
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
             const bool take = verdict[16 * ct + c] != 0;
+            const int chain = base + 16 * ct + c;
 #pragma unroll
             for (int t = 0; t < TI; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) x[t][ct][r] = take ? xp[t][ct][r] : x[t][ct][r];
+                for (int r = 0; r < 4; ++r) {
+                    if constexpr (LIKE == SMCMC_LIKE_QUADFORM) {
+                        // the accepted point was given up for the row sums: HBM holds it
+                        const int i = comp(t, r);
+                        const bool mine = owns(t) && i < D;
+                        if (take) {
+                            if (mine && chain < p.nchains) p.x[(size_t)i * NP + chain] = xp[t][ct][r];
+                            x[t][ct][r] = xp[t][ct][r];
+                        } else {
+                            x[t][ct][r] = mine ? p.x[(size_t)i * NP + chain] : 0.0;
+                        }
+                    } else {
+                        x[t][ct][r] = take ? xp[t][ct][r] : x[t][ct][r];
+                    }
+                }
         }
         if (p.save_x != nullptr && ((s + 1) % p.save_stride) == 0) {
             const size_t sl = (size_t)((s + 1) / p.save_stride - 1);

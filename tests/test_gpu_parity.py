@@ -366,6 +366,36 @@ def test_pooled_large_dim_matches_oracle(gpu, oracle, dim, nchains, stride, wind
     _assert_same_state(e, o, "after the last sync")
 
 
+@pytest.mark.parametrize("mode", ["frozen", "pooled"])
+@pytest.mark.parametrize("dim,nchains", [(64, 70), (100, 96), (300, 64)])
+def test_quadratic_form_at_large_dim_in_the_fused_order(gpu, oracle, mode, dim, nchains):
+    """TDummyLogLikelihood (header form, TDummyLogLikelihood.H:21-31) for D > 63: the row sums of Error p on
+    the matrix pipe, the outer sum in dimension order (the oracle's quadform_rowwise association)."""
+    m = gpu.MODE_FROZEN if mode == "frozen" else gpu.MODE_POOLED
+    e, o = _pair(gpu, oracle, dim, nchains, 1, m, False)
+    o.set_quadform_rowwise(1)
+    if mode == "pooled":
+        e.set_param("MOMENT_STRIDE", 2)
+        o.set_moment_grouping(int(e.get_param("MOMENT_GROUP")), 2)
+    x0 = np.full(dim, 0.05)
+    assert e.Start(x0) and o.start(x0)
+    _assert_same_state(e, o, "after start")
+    for w in range(2):
+        e.Step(6); o.step(6)
+        _assert_same_state(e, o, f"{mode} window {w}")
+        if mode == "pooled":
+            e.sync(); o.sync()
+            assert np.array_equal(e.decomposition, o.decomposition)
+    assert e.lane("naccept").sum() > 0
+
+
+def test_quadratic_form_at_large_dim_needs_the_fused_order(gpu, oracle):
+    e = gpu.Engine(100, 64, likelihood=1, likelihood_params=oracle.like_params(1, 100))
+    with pytest.raises(gpu.SmcmcError) as err:
+        e.Start(np.zeros(100))
+    assert err.value.status == 5   # SMCMC_ERR_UNSUPPORTED
+
+
 # ---------------------------------------------------------------- uniform dimensions and scan
 @pytest.mark.parametrize("mode", ["frozen", "pooled"])
 @pytest.mark.parametrize("kind,dim,nchains", [(0, 5, 70), (2, 6, 64), (0, 50, 128)])

@@ -48,6 +48,15 @@ dt = timed(lambda: e.Step(32), 3)
 out["config4_iso_d500_32768_frozen_fused_matrix_pipe"] = {
     "chain_steps_per_s": 32768 * 32 / dt, "ms_per_step": dt / 32 * 1e3,
     "proposal_TFLOPs": 32768 * 32 / dt * 500 * 501 / 1e12}
+# config 4 with the header-form TDummyLogLikelihood (quadratic form, Error from Init()): fused order only at D > 63
+from oracle import oracle as O  # noqa: E402  (only for TDummyLogLikelihood::Init's Error matrix)
+err = O.dummy_error_matrix(500)[1]
+e = pkg.Engine(500, 32768, likelihood=pkg.LIKE_QUADFORM, likelihood_params=err, mode=pkg.MODE_FROZEN, exact=False)
+e.Start(np.zeros(500))
+dt = timed(lambda: e.Step(32), 3)
+out["config4_tdummy_quadform_d500_32768_frozen_fused_matrix_pipe"] = {
+    "chain_steps_per_s": 32768 * 32 / dt, "ms_per_step": dt / 32 * 1e3,
+    "matrix_TFLOPs": 32768 * 32 / dt * (500 * 501 + 2 * 500 * 500) / 1e12}
 # configs 3 and 4 with the pooled covariance: moment fold every 16th step, sync every 256 steps (BASELINE config 4)
 for name, dim, n, kind, prm in (("config3_rosenbrock_d200_16384_pooled", 200, 16384, pkg.LIKE_ROSENBROCK, [100.0]),
                                ("config4_iso_d500_32768_pooled", 500, 32768, pkg.LIKE_ISO_GAUSS, None)):
@@ -64,8 +73,6 @@ for name, dim, n, kind, prm in (("config3_rosenbrock_d200_16384_pooled", 200, 16
             "chain_steps_per_s": n * 256 / dt, "ms_per_step": dt / 256 * 1e3,
             "accept": float(e.lane("naccept").sum() / (e.get_param("TOTAL_STEPS") * n))}
 # config 5: HMC, header TDummy D=500 (Error from Init()), 8 192 chains x 20 leapfrog steps
-from oracle import oracle as O  # noqa: E402  (only for TDummyLogLikelihood::Init's Error matrix)
-err = O.dummy_error_matrix(500)[1]
 for tag, exact, nstep in (("reference_order", True, 2), ("fused_order_matrix_pipe", False, 20)):
     h = pkg.HmcEngine(500, 8192, likelihood=pkg.LIKE_QUADFORM, likelihood_params=err, exact=exact)
     h.Start(np.ones(500)); h.SetMeanEpsilon(-0.0005); h.SetLeapFrog(20)

@@ -265,6 +265,43 @@ class Engine:
         return x.value, l.value
 
 
+class PosteriorMoments:
+    """Posterior mean / covariance of everything the ensemble visits (the reducers of
+    MakeCovariance.C:63-89), fed by the pooled moment sums the device already forms:
+
+        e.Step(window); e.reduce_moments(); acc.add(e); e.apply_moments()
+
+    Each window's packed vector M holds n, sum(x - c0) and sum (x - c0)(x - c0)^T about the centre c0 the
+    window ran with; they are re-centred on zero here and added up on the host (a few KB per window)."""
+
+    def __init__(self, dim):
+        self.dim = dim
+        self.n = 0.0
+        self.s1 = np.zeros(dim)
+        self.s2 = np.zeros((dim, dim))
+
+    def add(self, engine):
+        D = self.dim
+        m = engine.read_moments()
+        c0 = engine.GetEstimatedCenter()
+        tri = np.zeros((D + 1, D + 1))
+        tri[np.tril_indices(D + 1)] = m
+        n, s1 = tri[D, D], tri[D, :D]
+        s2 = tri[:D, :D] + np.tril(tri[:D, :D], -1).T
+        self.n += n
+        self.s1 += s1 + n * c0
+        self.s2 += s2 + np.outer(c0, s1) + np.outer(s1, c0) + n * np.outer(c0, c0)
+
+    @property
+    def mean(self):
+        return self.s1 / self.n
+
+    @property
+    def covariance(self):
+        mu = self.mean
+        return self.s2 / self.n - np.outer(mu, mu)
+
+
 def selftest_detmath(kind, x, y=None, device=0):
     lib = _capi.load()
     x = _f64(x)

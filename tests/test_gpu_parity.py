@@ -534,3 +534,25 @@ def test_restore_needs_start(gpu):
               central_point_trials=10.0, covariance=np.eye(4)[np.tril_indices(4)], covariance_trials=10.0)
     with pytest.raises(gpu.SmcmcError):
         e.Restore(st)
+
+
+# ---------------------------------------------------------------- posterior known answers
+def test_posterior_moments_of_known_targets(gpu):
+    """SURVEY.md section 8(c) known answers on the device, through the posterior reducers (PosteriorMoments over
+    the pooled moment sums): iso-Gaussian -> mean 0, covariance I; quadratic form -> covariance Error^-1."""
+    rng = np.random.default_rng(8)
+    a = rng.standard_normal((6, 6))
+    cov_true = a @ a.T / 6.0 + np.eye(6)
+    for kind, dim, prm, target in ((0, 8, None, np.eye(8)), (1, 6, np.linalg.inv(cov_true), cov_true)):
+        e = gpu.Engine(dim, 4096, likelihood=kind, likelihood_params=prm, seed=31)
+        assert e.Start(np.zeros(dim))
+        for _ in range(12):                                   # adaptation
+            e.Step(100); e.sync()
+        acc = gpu.PosteriorMoments(dim)
+        for _ in range(25):
+            e.Step(100); e.reduce_moments(); acc.add(e); e.apply_moments()
+        assert acc.n == 4096 * 100 * 25
+        scale = np.sqrt(np.diag(target))
+        assert np.max(np.abs(acc.mean) / scale) < 0.02
+        assert np.max(np.abs(acc.covariance - target) / np.outer(scale, scale)) < 0.03
+        assert 0.15 < e.lane("acceptance").mean() < 0.40      # sigma still settling toward the 0.234 target

@@ -67,7 +67,8 @@ int tiles_for(int dp) {
 struct smcmc_engine {
     int dim = 0, nchains = 0, npad = 0, ngroups = 0, dp = 0, nt = 0;
     int moment_stride = 1;   // large-dimension path: fold the current point every moment_stride-th step
-    int slice_chains = 0;    // large-dimension path: chains per moment group (kFoldSlices groups)
+    int slice_chains = 0;    // large-dimension path: chains per moment group
+    int fold_nslices = 0;    // ... and the number of groups (fold_slices(dim))
     int panel_w = 0;   // 0: register-resident kernels (dim <= 63); 4 / 8: wavefronts per chain group of the panel kernel
     int likelihood = 0, mode = SMCMC_MODE_POOLED, device = 0;
     bool exact = true, started = false;
@@ -321,7 +322,7 @@ int launch(smcmc_engine* h, int nsteps, int metropolis, int stride, double* save
             if (pooled) {
                 const int phase = (int)(h->total_steps % (uint32_t)h->moment_stride);
                 if (phase == 0) {
-                    hipError_t e = launch_fold(h->d_x, h->d_c0, h->nchains, h->npad, h->dim, h->slice_chains, h->d_gacc,
+                    hipError_t e = launch_fold(h->d_x, h->d_c0, h->nchains, h->npad, h->dim, h->slice_chains, h->fold_nslices, h->d_gacc,
                                                h->stream);
                     if (e != hipSuccess) return fail(h, SMCMC_ERR_HIP, std::string("fold kernel launch: ") + hipGetErrorString(e));
                 }
@@ -413,7 +414,8 @@ int smcmc_create(int dim, int nchains, int likelihood, uint64_t seed, uint32_t c
     h->npad = (nchains + kWave - 1) / kWave * kWave;
     h->ngroups = h->npad / kWave;
     h->nt = panel_w ? 1 : tiles_for(dp);
-    h->slice_chains = ((h->ngroups + kFoldSlices - 1) / kFoldSlices) * kWave;
+    h->fold_nslices = fold_slices(dim);
+    h->slice_chains = ((h->ngroups + h->fold_nslices - 1) / h->fold_nslices) * kWave;
     h->prop = new SharedProposal(dim);
     *out = h;
     HIP_TRY(h, hipSetDevice(device));
@@ -807,7 +809,7 @@ int smcmc_moments_size(const smcmc_engine* h) { return h ? (int)npacked(h) : 0; 
 int smcmc_reduce_moments(smcmc_engine* h) {
     if (!h || !h->started) return SMCMC_ERR_INVALID;
     if (h->panel_w) {
-        hipError_t e = launch_fold_reduce(h->d_gacc, h->dim, h->d_moments, h->stream);
+        hipError_t e = launch_fold_reduce(h->d_gacc, h->dim, h->fold_nslices, h->d_moments, h->stream);
         if (e != hipSuccess) return fail(h, SMCMC_ERR_HIP, std::string("fold reduce launch: ") + hipGetErrorString(e));
         HIP_TRY(h, hipMemsetAsync(h->d_gacc, 0, sizeof(double) * gacc_doubles(h), h->stream));
         return SMCMC_OK;

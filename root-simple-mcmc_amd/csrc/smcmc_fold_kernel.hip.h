@@ -18,7 +18,16 @@
 
 namespace smcmc {
 
-constexpr int kFoldSlices = 32;   // chain slices (moment groups) of the large-dimension path
+constexpr int kFoldSlices = 32;   // most chain slices (moment groups) of the large-dimension path
+// Slices actually used: as many as give every SIMD of the 256 CUs at most one wavefront (blocks x slices <=
+// 1024), a multiple of the workgroup's wavefronts, so that a fold is one round of workgroups with no tail.
+inline int fold_slices(int D) {
+    const int T = (D + 1 + 15) / 16, TB = (T + 3) / 4, nblocks = TB * (TB + 1) / 2;
+    int n = 4 * (256 / nblocks);
+    if (n > kFoldSlices) n = kFoldSlices;
+    if (n < 4) n = 4;
+    return n;
+}
 constexpr int kFoldBT = 4;        // a wavefront folds a block of kFoldBT x kFoldBT tiles (64 x 64 moments)
 
 // row r of the augmented point y: dims 0..D-1, the constant 1 at r == D, zero above
@@ -30,25 +39,39 @@ __device__ __forceinline__ double fold_operand(const double* __restrict__ x, siz
 }
 
 // grid = (nblocks, kFoldSlices), block = 64.  block -> (bi, bj <= bi) of 4 x 4 tiles: eight operand
-// reads feed sixteen matrix instructions (a quarter of the state traffic of one tile per wavefront).
-static __global__ void __launch_bounds__(kWave) fold_moments_kernel(const double* __restrict__ x, const double* __restrict__ c0,
+// tiles feed sixteen matrix instructions.  The state is read in full cache lines (lane -> row
+// lane >> 2, four consecutive chains), one stage of 16 chains ahead of its use, and re-laid out
+// through LDS into the operand layout (row lane & 15, chain 4 n + (lane >> 4)).
+// Four wavefronts per workgroup (four slices of the same block) and more than half of a CU's LDS per
+// workgroup: one workgroup per CU, one wavefront per SIMD -- single-wavefront workgroups stack up on a
+// few CUs instead and leave the rest idle.
+constexpr int kFoldWaves = 4;
+static __global__ void __launch_bounds__(kFoldWaves* kWave) fold_moments_kernel(const double* __restrict__ x, const double* __restrict__ c0,
                                                              int nchains, int npad, int D, int slice_chains,
                                                              double* __restrict__ gacc) {
-    const int lane = threadIdx.x;
-    const int slice = blockIdx.y;
+    constexpr int kS = 18;   // doubles per staged row: 16 chains + 2 (operand reads spread over the banks)
+    __shared__ __attribute__((aligned(16))) double st_all[kFoldWaves][2 * kFoldBT][16][kS];
+    __shared__ double occupancy_pad[1100];   // pushes the workgroup past 80 KB of LDS: one workgroup per CU
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wv = threadIdx.x / kWave;
+    if (threadIdx.x == 0 && D < 0) occupancy_pad[0] = 0.0;   // keeps the array (never true)
+    double (*st)[16][kS] = st_all[wv];
+    const int slice = blockIdx.y * kFoldWaves + wv;
     const int T = (D + 1 + 15) / 16, ntiles = T * (T + 1) / 2;
     int bi = 0;
     while ((bi + 1) * (bi + 2) / 2 <= (int)blockIdx.x) ++bi;
     const int bj = (int)blockIdx.x - bi * (bi + 1) / 2;
+    const bool diagonal = (bi == bj);
     const size_t NP = (size_t)npad;
-    int ra[kFoldBT], rb[kFoldBT];
-    double ca[kFoldBT], cb[kFoldBT];
+    // staging role of this lane: row (lane >> 2) of every operand tile, chains 4 (lane & 3) .. + 3
+    const int srow = lane >> 2, sq = lane & 3;
+    int rr[2 * kFoldBT];
+    double cc[2 * kFoldBT];
 #pragma unroll
-    for (int a = 0; a < kFoldBT; ++a) {
-        ra[a] = 16 * (kFoldBT * bi + a) + (lane & 15);
-        rb[a] = 16 * (kFoldBT * bj + a) + (lane & 15);
-        ca[a] = (ra[a] < D) ? c0[ra[a]] : 0.0;
-        cb[a] = (rb[a] < D) ? c0[rb[a]] : 0.0;
+    for (int op = 0; op < 2 * kFoldBT; ++op) {
+        const int tile = (op < kFoldBT) ? kFoldBT * bi + op : kFoldBT * bj + (op - kFoldBT);
+        rr[op] = 16 * tile + srow;
+        cc[op] = (rr[op] < D) ? c0[rr[op]] : 0.0;
     }
     // tile (ti, tj) of the block: valid when it exists and lies in the lower triangle
     auto valid = [&](int a, int b) { return kFoldBT * bi + a < T && kFoldBT * bj + b <= kFoldBT * bi + a; };
@@ -65,20 +88,63 @@ static __global__ void __launch_bounds__(kWave) fold_moments_kernel(const double
             for (int r = 0; r < 4; ++r) acc[a][b][r] = valid(a, b) ? gacc[offset(a, b) + (size_t)r * kWave] : 0.0;
     const int c_begin = slice * slice_chains;
     const int c_end = (c_begin + slice_chains < npad) ? c_begin + slice_chains : npad;
-#pragma unroll 8
-    for (int c = c_begin; c < c_end; c += 4) {
-        const int chain = c + (lane >> 4);
-        double av[kFoldBT], bv[kFoldBT];
+    const int nops = diagonal ? kFoldBT : 2 * kFoldBT;   // a diagonal block's column operands are its row operands
+
+    typedef f64x2 stage_t[2 * kFoldBT][2];
+    stage_t stA, stB;   // two stages of 16 chains in flight ahead of the matrix instructions
+    auto fetch = [&](int c, stage_t& stage) {   // y = x - c0 (the constant 1 in row D, 0 above, 0 for chains past the ensemble)
 #pragma unroll
-        for (int a = 0; a < kFoldBT; ++a) {
-            av[a] = fold_operand(x, NP, D, ra[a], chain, nchains, ca[a]);
-            bv[a] = fold_operand(x, NP, D, rb[a], chain, nchains, cb[a]);
+        for (int op = 0; op < 2 * kFoldBT; ++op) {
+            if (op >= nops) continue;
+            const int chain = c + 4 * sq;
+            f64x2 v0 = {0.0, 0.0}, v1 = {0.0, 0.0};
+            if (rr[op] < D) {
+                const f64x2* src = (const f64x2*)(x + (size_t)rr[op] * NP + chain);
+                v0 = src[0];
+                v1 = src[1];
+                v0[0] -= cc[op]; v0[1] -= cc[op]; v1[0] -= cc[op]; v1[1] -= cc[op];
+            } else if (rr[op] == D) {
+                v0[0] = v0[1] = v1[0] = v1[1] = 1.0;
+            }
+            if (chain + 0 >= nchains) v0[0] = 0.0;
+            if (chain + 1 >= nchains) v0[1] = 0.0;
+            if (chain + 2 >= nchains) v1[0] = 0.0;
+            if (chain + 3 >= nchains) v1[1] = 0.0;
+            stage[op][0] = v0;
+            stage[op][1] = v1;
         }
+    };
+    // one stage: registers -> LDS, refill the registers two stages ahead, fold the 16 chains
+    auto consume = [&](int c, stage_t& stage) {
+        __syncthreads();   // the previous stage has been consumed
 #pragma unroll
-        for (int a = 0; a < kFoldBT; ++a)
+        for (int op = 0; op < 2 * kFoldBT; ++op) {
+            if (op >= nops) continue;
+            *(f64x2*)&st[op][srow][4 * sq] = stage[op][0];
+            *(f64x2*)&st[op][srow][4 * sq + 2] = stage[op][1];
+        }
+        __syncthreads();
+        if (c + 32 < c_end) fetch(c + 32, stage);   // in flight under the matrix instructions
 #pragma unroll
-            for (int b = 0; b < kFoldBT; ++b)
-                if (valid(a, b)) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], acc[a][b], 0, 0, 0);
+        for (int n = 0; n < 4; ++n) {
+            double av[kFoldBT], bv[kFoldBT];
+#pragma unroll
+            for (int a = 0; a < kFoldBT; ++a) {
+                av[a] = st[a][lane & 15][4 * n + (lane >> 4)];
+                bv[a] = diagonal ? av[a] : st[kFoldBT + a][lane & 15][4 * n + (lane >> 4)];
+            }
+#pragma unroll
+            for (int a = 0; a < kFoldBT; ++a)
+#pragma unroll
+                for (int b = 0; b < kFoldBT; ++b)
+                    if (valid(a, b)) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], acc[a][b], 0, 0, 0);
+        }
+    };
+    if (c_begin < c_end) fetch(c_begin, stA);
+    if (c_begin + 16 < c_end) fetch(c_begin + 16, stB);
+    for (int c = c_begin; c < c_end; c += 32) {
+        consume(c, stA);
+        if (c + 16 < c_end) consume(c + 16, stB);
     }
 #pragma unroll
     for (int a = 0; a < kFoldBT; ++a)
@@ -108,8 +174,8 @@ static __global__ void fold_reduce_kernel(const double* __restrict__ gacc, int n
     moments[k] = s;
 }
 
-hipError_t launch_fold(const double* x, const double* c0, int nchains, int npad, int D, int slice_chains,
+hipError_t launch_fold(const double* x, const double* c0, int nchains, int npad, int D, int slice_chains, int nslices,
                        double* gacc, hipStream_t stream);
-hipError_t launch_fold_reduce(const double* gacc, int D, double* moments, hipStream_t stream);
+hipError_t launch_fold_reduce(const double* gacc, int D, int nslices, double* moments, hipStream_t stream);
 
 }  // namespace smcmc

@@ -31,18 +31,19 @@ hipError_t launch_panel<SMCMC_PANEL_W, kPanelCW>(const PanelParams& p, int like,
 }
 
 #if SMCMC_PANEL_W == 4
-hipError_t launch_fold(const double* x, const double* c0, int nchains, int npad, int D, int slice_chains,
+hipError_t launch_fold(const double* x, const double* c0, int nchains, int npad, int D, int slice_chains, int nslices,
                        double* gacc, hipStream_t s) {
     const int T = (D + 1 + 15) / 16, TB = (T + kFoldBT - 1) / kFoldBT, nblocks = TB * (TB + 1) / 2;
-    hipLaunchKernelGGL(fold_moments_kernel, dim3(nblocks, kFoldSlices), dim3(kWave), 0, s, x, c0, nchains, npad, D,
-                       slice_chains, gacc);
+    if (nslices < kFoldWaves || nslices % kFoldWaves != 0 || nslices > kFoldSlices) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(fold_moments_kernel, dim3(nblocks, nslices / kFoldWaves), dim3(kFoldWaves * kWave), 0, s, x, c0,
+                       nchains, npad, D, slice_chains, gacc);
     return hipGetLastError();
 }
 
-hipError_t launch_fold_reduce(const double* gacc, int D, double* moments, hipStream_t s) {
+hipError_t launch_fold_reduce(const double* gacc, int D, int nslices, double* moments, hipStream_t s) {
     const int T = (D + 1 + 15) / 16, ntiles = T * (T + 1) / 2;
     const int npk = (D + 1) * (D + 2) / 2;
-    hipLaunchKernelGGL(fold_reduce_kernel, dim3((npk + 255) / 256), dim3(256), 0, s, gacc, ntiles, kFoldSlices, D,
+    hipLaunchKernelGGL(fold_reduce_kernel, dim3((npk + 255) / 256), dim3(256), 0, s, gacc, ntiles, nslices, D,
                        moments);
     return hipGetLastError();
 }

@@ -163,13 +163,13 @@ int upload_shared(smcmc_engine* h) {
         HIP_TRY(h, hipMemcpyAsync(h->d_U, perm.data(), perm.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
         if (!h->exact && !h->prop->decompFull) {
             // Uop[(tile * nkq + kq) * 64 + lane] = U(4 kq + (lane >> 4), 16 tile + (lane & 15))
-            const int ntiles = (D + 15) / 16, nkq = (D + 3) / 4;
+            const int ntiles = (D + 15) / 16, nkq = (D + 3) / 4, nkqp = panel_mfma_nkq_padded(D);
             std::vector<double> uop(panel_mfma_uop_doubles(D), 0.0);
             for (int jt = 0; jt < ntiles; ++jt)
                 for (int kq = 0; kq < nkq; ++kq)
                     for (int l = 0; l < 64; ++l) {
                         const int i = 4 * kq + (l >> 4), j = 16 * jt + (l & 15);
-                        if (i < D && j < D) uop[((size_t)jt * nkq + kq) * 64 + l] = h->prop->decomp[(size_t)i * D + j];
+                        if (i < D && j < D) uop[((size_t)jt * nkqp + kq) * 64 + l] = h->prop->decomp[(size_t)i * D + j];
                     }
             HIP_TRY(h, hipMemcpyAsync(h->d_Uop, uop.data(), uop.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
         }
@@ -209,13 +209,13 @@ int upload_like(smcmc_engine* h) {
                 return fail(h, SMCMC_ERR_UNSUPPORTED,
                             "the quadratic-form likelihood for dim > 63 runs in the fused order only "
                             "(SMCMC_P_EXACT_ARITHMETIC = 0): its reference order is one serial D^2-term sum per chain");
-            const int ntiles = (D + 15) / 16, nkq = (D + 3) / 4;
+            const int ntiles = (D + 15) / 16, nkq = (D + 3) / 4, nkqp = panel_mfma_nkq_padded(D);
             std::vector<double> eop(panel_mfma_uop_doubles(D), 0.0);
             for (int it = 0; it < ntiles; ++it)
                 for (int kq = 0; kq < nkq; ++kq)
                     for (int l = 0; l < 64; ++l) {
                         const int i = 16 * it + (l & 15), j = 4 * kq + (l >> 4);
-                        if (i < D && j < D) eop[((size_t)it * nkq + kq) * 64 + l] = h->like_params[(size_t)i * D + j];
+                        if (i < D && j < D) eop[((size_t)it * nkqp + kq) * 64 + l] = h->like_params[(size_t)i * D + j];
                     }
             HIP_TRY(h, hipMemcpyAsync(h->d_like, eop.data(), eop.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
             HIP_TRY(h, hipStreamSynchronize(h->stream));

@@ -161,13 +161,13 @@ int smcmc_hmc_start(smcmc_hmc* h, const double* x0, int broadcast) {
         if (h->use_mfma) {
             // Eop[(tile * nkq + kq) * 64 + lane] = Error(16 tile + (lane & 15), 4 kq + (lane >> 4)): the A operand
             // of every matrix instruction as one contiguous 512-byte read
-            const int ntiles = (D + 15) / 16, nkq = (D + 3) / 4;
+            const int ntiles = (D + 15) / 16, nkq = (D + 3) / 4, nkqp = panel_mfma_nkq_padded(D);
             std::vector<double> eop(hmc_mfma_eop_doubles(D), 0.0);
             for (int it = 0; it < ntiles; ++it)
                 for (int kq = 0; kq < nkq; ++kq)
                     for (int l = 0; l < 64; ++l) {
                         const int i = 16 * it + (l & 15), j = 4 * kq + (l >> 4);
-                        if (i < D && j < D) eop[((size_t)it * nkq + kq) * 64 + l] = h->like_params[(size_t)i * D + j];
+                        if (i < D && j < D) eop[((size_t)it * nkqp + kq) * 64 + l] = h->like_params[(size_t)i * D + j];
                     }
             HMC_TRY(h, hipMemcpyAsync(h->d_E, eop.data(), eop.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
             HMC_TRY(h, hipStreamSynchronize(h->stream));

@@ -29,6 +29,7 @@
 #include "smcmc.h"
 #include "smcmc_detmath.h"
 #include "smcmc_hmc_kernel.hip.h"
+#include "smcmc_panel_mfma_kernel.hip.h"
 
 namespace smcmc {
 
@@ -37,11 +38,9 @@ constexpr int kMfW = 8;                              // wavefronts per workgroup
 constexpr int kMfTIMax = 4;                          // 16-component tiles per wavefront: dim <= 512
 constexpr int kMfDimMax = 16 * kMfW * kMfTIMax;
 
-// Eop[(tile * nkq + kq) * 64 + lane] = Error(16 tile + (lane & 15), 4 kq + (lane >> 4)), zero padded
-inline size_t hmc_mfma_eop_doubles(int dim) {
-    const int ntiles = (dim + 15) / 16, nkq = (dim + 3) / 4;
-    return (size_t)ntiles * nkq * 64;
-}
+// Eop[(tile * nkqp + kq) * 64 + lane] = Error(16 tile + (lane & 15), 4 kq + (lane >> 4)), zero padded
+// (k-quads per tile rounded up to the prefetch depth of pm_contract, zero padded)
+inline size_t hmc_mfma_eop_doubles(int dim) { return panel_mfma_uop_doubles(dim); }
 
 // TI = 16-component tiles a wavefront owns: dim <= 128 TI
 template <int kMfTI>
@@ -58,7 +57,7 @@ __global__ void __launch_bounds__(kMfW* kWave, 1) hmc_mfma_kernel(const HmcParam
     // the row stride is re-read through an opaque copy every step: otherwise the 96 element addresses of
     // q, pm and qn are hoisted out of the step loop as 64-bit values and spilled
     size_t NP = (size_t)p.npad;
-    const int ntiles = (D + 15) / 16, nkq = (D + 3) / 4;
+    const int ntiles = (D + 15) / 16, nkqp = panel_mfma_nkq_padded(D);
     const uint32_t ew = smcmc_accept_word((uint32_t)D);
 
     // this lane's chains (one per chain tile) and, for the summing lanes of wavefront 0, `mychain`
@@ -102,17 +101,11 @@ __global__ void __launch_bounds__(kMfW* kWave, 1) hmc_mfma_kernel(const HmcParam
         for (int t = 0; t < kMfTI; ++t)
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct) gr[t][ct] = f64x4v{0.0, 0.0, 0.0, 0.0};
-        const double* eop = p.Eperm + lane;
-        for (int kq = 0; kq < nkq; ++kq) {
-            const double b0 = qs[(4 * kq + rq) * kMfCT + c];
-            const double b1 = qs[(4 * kq + rq) * kMfCT + 16 + c];
+        const double* qs_lane = qs + rq * kMfCT + c;
 #pragma unroll
-            for (int t = 0; t < kMfTI; ++t) {
-                if (!owns(t)) continue;
-                const double a = eop[((size_t)(t * kMfW + w) * nkq + kq) * 64];
-                gr[t][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0, gr[t][0], 0, 0, 0);
-                gr[t][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b1, gr[t][1], 0, 0, 0);
-            }
+        for (int t = 0; t < kMfTI; ++t) {
+            if (!owns(t)) continue;
+            pm_contract(p.Eperm + lane + (size_t)(t * kMfW + w) * nkqp * 64, qs_lane, nkqp, gr[t][0], gr[t][1]);
         }
         __syncthreads();   // the positions may be overwritten again
     };
@@ -141,6 +134,11 @@ __global__ void __launch_bounds__(kMfW* kWave, 1) hmc_mfma_kernel(const HmcParam
         publish([&](int t, int ct, int r) { return pn[t][ct][r] * pn[t][ct][r] / 2.0; });
         return ordered_sum();
     };
+
+    // rows past the last owned tile (the contraction runs to a multiple of the prefetch depth) are never
+    // published: they must hold zeros, not whatever the LDS held before
+    for (int k = threadIdx.x; k < 16 * kMfW * kMfTI * kMfCT; k += kMfW * kWave) qs[k] = 0.0;
+    __syncthreads();
 
     // per-chain state lives in the summing lanes
     double pot_acc = 0.0, pot_prop = 0.0, acceptance = 0.0;

@@ -38,9 +38,40 @@ namespace smcmc {
 constexpr int kPmCT = 32;   // chains per workgroup
 constexpr int kPmW = 8;     // wavefronts per workgroup
 
+constexpr int kPmPF = 8;    // k-quads of the A operand fetched ahead of the matrix instructions
+
+// k-quads per tile in the operand images (U^T, Error): rounded up to the prefetch depth, zero padded
+__host__ __device__ inline int panel_mfma_nkq_padded(int dim) { return ((dim + 3) / 4 + kPmPF - 1) / kPmPF * kPmPF; }
 inline size_t panel_mfma_uop_doubles(int dim) {
-    const int ntiles = (dim + 15) / 16, nkq = (dim + 3) / 4;
-    return (size_t)ntiles * nkq * 64;
+    const int ntiles = (dim + 15) / 16;
+    return (size_t)ntiles * panel_mfma_nkq_padded(dim) * 64;
+}
+
+// acc0/acc1 += A(tile rows, k) * z(k, chains 0-15 / 16-31) over k-quads [0, kend), kend a multiple of kPmPF:
+// the A operands (one coalesced 512-byte read per k-quad) run kPmPF k-quads ahead of their use.  Used for
+// the full-length contractions (Error p, Error q); the triangular proposal, whose tiles are short and whose
+// kernel is tighter on registers, measured faster with the plain loop.
+template <typename F4>
+__device__ __forceinline__ void pm_contract(const double* __restrict__ a_ptr, const double* qs_lane, int kend,
+                                            F4& acc0, F4& acc1) {
+    double a0[kPmPF], a1[kPmPF];
+#pragma unroll
+    for (int u = 0; u < kPmPF; ++u) a0[u] = (kend > 0) ? a_ptr[(size_t)u * 64] : 0.0;
+    for (int kq0 = 0; kq0 < kend; kq0 += kPmPF) {
+        if (kq0 + kPmPF < kend) {
+#pragma unroll
+            for (int u = 0; u < kPmPF; ++u) a1[u] = a_ptr[(size_t)(kq0 + kPmPF + u) * 64];
+        }
+#pragma unroll
+        for (int u = 0; u < kPmPF; ++u) {
+            const double b0 = qs_lane[(size_t)(4 * (kq0 + u)) * 32];
+            const double b1 = qs_lane[(size_t)(4 * (kq0 + u)) * 32 + 16];
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b1, acc1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < kPmPF; ++u) a0[u] = a1[u];
+    }
 }
 
 // TI = 16-component tiles per wavefront: dim <= 128 TI
@@ -57,7 +88,7 @@ __global__ void __launch_bounds__(kPmW* kWave, 1) panel_mfma_kernel(const PanelP
     const int base = blockIdx.x * kPmCT;
     const int D = p.dim;
     const size_t NP = (size_t)p.npad;
-    const int ntiles = (D + 15) / 16, nkq = (D + 3) / 4;
+    const int ntiles = (D + 15) / 16, nkq = (D + 3) / 4, nkqp = panel_mfma_nkq_padded(D);
     const uint32_t aw = smcmc_accept_word((uint32_t)D);
     const double rb = (LIKE == SMCMC_LIKE_ROSENBROCK) ? p.like[0] : 0.0;
 
@@ -139,17 +170,11 @@ __global__ void __launch_bounds__(kPmW* kWave, 1) panel_mfma_kernel(const PanelP
             gr[t][0] = f64x4v{0.0, 0.0, 0.0, 0.0};
             gr[t][1] = f64x4v{0.0, 0.0, 0.0, 0.0};
         }
-        const double* eop = p.like + lane;
-        for (int kq = 0; kq < nkq; ++kq) {
-            const double b0 = qs[(4 * kq + rq) * kPmCT + c];
-            const double b1 = qs[(4 * kq + rq) * kPmCT + 16 + c];
+        const double* qs_lane = qs + rq * kPmCT + c;
 #pragma unroll
-            for (int t = 0; t < TI; ++t) {
-                if (!owns(t)) continue;
-                const double a = eop[((size_t)tile(t) * nkq + kq) * 64];
-                gr[t][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0, gr[t][0], 0, 0, 0);
-                gr[t][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b1, gr[t][1], 0, 0, 0);
-            }
+        for (int t = 0; t < TI; ++t) {
+            if (!owns(t)) continue;
+            pm_contract(p.like + lane + (size_t)tile(t) * nkqp * 64, qs_lane, nkqp, gr[t][0], gr[t][1]);
         }
 #pragma unroll
         for (int t = 0; t < TI; ++t)
@@ -246,7 +271,7 @@ __global__ void __launch_bounds__(kPmW* kWave, 1) panel_mfma_kernel(const PanelP
                 if (!owns(t)) continue;
                 const int jt = tile(t);
                 const int kend = (4 * jt + 4 < nkq) ? 4 * jt + 4 : nkq;   // U(i, j) = 0 for i > j
-                const double* ut = uop + (size_t)jt * nkq * 64;
+                const double* ut = uop + (size_t)jt * nkqp * 64;
                 for (int kq = 0; kq < kend; ++kq) {
                     const double a = ut[(size_t)kq * 64];
                     const double b0 = qs[(4 * kq + rq) * kPmCT + c];

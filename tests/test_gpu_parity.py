@@ -556,3 +556,28 @@ def test_posterior_moments_of_known_targets(gpu):
         assert np.max(np.abs(acc.mean) / scale) < 0.02
         assert np.max(np.abs(acc.covariance - target) / np.outer(scale, scale)) < 0.03
         assert 0.15 < e.lane("acceptance").mean() < 0.40      # sigma still settling toward the 0.234 target
+
+
+def test_config1_a_million_steps_bit_for_bit(gpu, oracle):
+    """BASELINE config 1 (D=5, 10^6 Step() calls of one chain, `SimpleMCMC.C` defaults) on the device next to
+    the CPU restatement: after a million steps every lane is still bit for bit the reference chain with its
+    chain id (frozen covariance: the ensemble shares no state), and the visited points have the posterior's
+    mean and covariance."""
+    dim, steps = 5, 1000000
+    e = gpu.Engine(dim, 64, mode=gpu.MODE_FROZEN)
+    assert e.Start(np.zeros(dim))
+    e.Step(steps)
+    x = e.GetAccepted()
+    for ch in (0, 63):
+        c = oracle.Chain(dim, chain_id=ch)
+        c.set_covariance_frozen(1)
+        assert c.start(np.zeros(dim))
+        c.run_quiet(steps)
+        sc = c.scalars
+        assert np.array_equal(c.accepted, x[:, ch])
+        assert sc["accepted_logl"] == e.GetAcceptedLogLikelihood()[ch]
+        assert sc["sigma"] == e.lane("sigma")[ch] and sc["acceptance"] == e.lane("acceptance")[ch]
+        assert sc["trials"] == e.lane("trials")[ch] == steps and sc["successes"] == e.lane("successes")[ch]
+        assert sc["next_update"] == e.lane("next_update")[ch] and sc["step_rms"] == e.lane("step_rms")[ch]
+    acc = e.lane("naccept") / steps
+    assert np.all(np.abs(acc - 0.234) < 0.02)                 # every chain settled on the target acceptance

@@ -3,9 +3,10 @@
 // For D > 63 the (D+1)(D+2)/2 accumulators of a 64-chain group no longer fit a
 // wavefront's registers, so the fold of the current point into the moment sums
 // (the batch form of the running covariance, reference TSimpleMCMC.H:1795-1820)
-// runs as its own kernel between step launches: one wavefront per (16x16 output
-// tile, chain slice), y = x - c0 read straight from the [dim][chain] state, chains
-// of the slice folded in ascending order by a chain of v_mfma_f64_16x16x4_f64.
+// runs as its own kernel between step launches: one wavefront per (4 x 4 block of
+// 16x16 output tiles, chain slice), y = x - c0 from the [dim][chain] state (staged
+// through LDS in full cache lines), chains of the slice folded in ascending order by
+// chains of v_mfma_f64_16x16x4_f64.
 // The accumulators persist in HBM across folds; the slice sums are added in slice
 // order by fold_reduce_kernel.  oracle/ensemble_oracle.c mirrors this order with
 // moment groups of `slice_chains` chains.
@@ -30,15 +31,7 @@ inline int fold_slices(int D) {
 }
 constexpr int kFoldBT = 4;        // a wavefront folds a block of kFoldBT x kFoldBT tiles (64 x 64 moments)
 
-// row r of the augmented point y: dims 0..D-1, the constant 1 at r == D, zero above
-__device__ __forceinline__ double fold_operand(const double* __restrict__ x, size_t NP, int D, int r, int chain,
-                                               int nchains, double c0r) {
-    if (chain >= nchains) return 0.0;
-    if (r < D) return x[(size_t)r * NP + chain] - c0r;
-    return (r == D) ? 1.0 : 0.0;
-}
-
-// grid = (nblocks, kFoldSlices), block = 64.  block -> (bi, bj <= bi) of 4 x 4 tiles: eight operand
+// grid = (nblocks, nslices / 4), block = 256.  block -> (bi, bj <= bi) of 4 x 4 tiles: eight operand
 // tiles feed sixteen matrix instructions.  The state is read in full cache lines (lane -> row
 // lane >> 2, four consecutive chains), one stage of 16 chains ahead of its use, and re-laid out
 // through LDS into the operand layout (row lane & 15, chain 4 n + (lane >> 4)).

@@ -46,7 +46,6 @@ inline size_t hmc_mfma_eop_doubles(int dim) { return panel_mfma_uop_doubles(dim)
 template <int kMfTI>
 __global__ void __launch_bounds__(kMfW* kWave, 1) hmc_mfma_kernel(const HmcParams p) {
     __shared__ double qs[16 * kMfW * kMfTI * kMfCT];   // [component][chain]: the published vector
-    __shared__ double red0[kMfCT], red1[kMfCT];
     __shared__ int verdict[kMfCT];
 
     const int lane = threadIdx.x & (kWave - 1);

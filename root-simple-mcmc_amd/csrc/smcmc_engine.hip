@@ -570,7 +570,12 @@ int smcmc_set_param(smcmc_engine* h, int which, double v) {
         case SMCMC_P_CENTER_TRIALS: P.centreTrials = v; return SMCMC_OK;
         case SMCMC_P_EXACT_ARITHMETIC:
             h->exact = (v != 0.0);
-            return h->started ? upload_shared(h) : SMCMC_OK;   // the fused order keeps its own operand image of U
+            if (h->started) {                                  // the fused order keeps its own operand images
+                int st = upload_like(h);
+                if (st) return st;
+                return upload_shared(h);
+            }
+            return SMCMC_OK;
         case SMCMC_P_MOMENT_STRIDE:
             if (v < 1.0) return fail(h, SMCMC_ERR_INVALID, "moment stride must be >= 1");
             if (!h->panel_w && v != 1.0)

@@ -1,0 +1,28 @@
+// user_likelihood_asym.hip.h -- a user likelihood for the MI355X engine: the reference's
+// TASymLogLikelihood (TAsymLogLikelihood.H:20-31: slope -1 above zero, +100 below, summed over the
+// dimensions) written as the device function the engine compiles in.
+//
+//   python root-simple-mcmc_amd/build.py --user-likelihood examples/user_likelihood_asym.hip.h
+//
+// gives lib/libsmcmc_amd_user.so, in which smcmc_create(..., SMCMC_LIKE_USER, ...) runs this function
+// inside the step kernel.  What the reference's `double operator()(const sMCMC::Vector& point)` becomes:
+// the point arrives as a register array p[0..D) (entries past D are zero), the functor's data members as
+// the parameter array handed to smcmc_set_likelihood_params, and the body keeps its operation order.
+#pragma once
+
+template <int DP>
+__device__ __forceinline__ double smcmc_user_loglike(const double (&p)[DP], smcmc::cptr_f64 params, int D) {
+    const double positiveSlope = params[0];   // -1.0  (TAsymLogLikelihood.H:16)
+    const double negativeSlope = params[1];   // 100.0 (:17)
+    double logLikelihood = 0.0;
+#pragma unroll
+    for (int i = 0; i < DP; ++i) {
+        if (i < D) {
+            double a = p[i];
+            if (a < 0.0) a *= negativeSlope;
+            else a *= positiveSlope;
+            logLikelihood += a;
+        }
+    }
+    return logLikelihood;
+}

@@ -42,7 +42,13 @@ typedef enum {
 typedef enum {
     SMCMC_LIKE_ISO_GAUSS = 0,   /* README.md:57-66 / TSimpleMCMC.H:111-120: logL = sum -0.5 p_i^2 */
     SMCMC_LIKE_QUADFORM = 1,    /* TDummyLogLikelihood.H:21-31; params = Error matrix, dim*dim row-major */
-    SMCMC_LIKE_ROSENBROCK = 2   /* THardLogLikelihood.H:57-67; params = {ROSEN_B}, default 100 */
+    SMCMC_LIKE_ROSENBROCK = 2,  /* THardLogLikelihood.H:57-67; params = {ROSEN_B}, default 100 */
+    /* A likelihood compiled in from user source (the `double operator()(const Vector&)` of the
+     * reference's UserLikelihood concept, TSimpleMCMC.H:53-57, as a device function): a library built
+     * with `python root-simple-mcmc_amd/build.py --user-likelihood my_likelihood.hip.h` carries it
+     * (INTEGRATION.md); other builds answer SMCMC_ERR_UNSUPPORTED.  dim <= 63; params = whatever the
+     * function reads (at most dim_padded^2 doubles). */
+    SMCMC_LIKE_USER = 3
 } smcmc_likelihood;
 
 /* How the proposal covariance adapts over the ensemble. */

@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(HERE, "lib", "libsmcmc_amd.so")
 
 OK, ERR_INVALID, ERR_LOGIC, ERR_RUNTIME, ERR_BAD_START, ERR_UNSUPPORTED, ERR_HIP, ERR_NO_DEVICE = range(8)
 
-LIKE_ISO_GAUSS, LIKE_QUADFORM, LIKE_ROSENBROCK = 0, 1, 2
+LIKE_ISO_GAUSS, LIKE_QUADFORM, LIKE_ROSENBROCK, LIKE_USER = 0, 1, 2, 3
 MODE_FROZEN, MODE_POOLED = 0, 1
 
 PARAMS = ["COVARIANCE_WINDOW", "COVARIANCE_DEWEIGHT", "ACCEPTANCE_WINDOW", "ACCEPTANCE_DEWEIGHT",
@@ -104,6 +104,7 @@ SIGNATURES = {
 }
 
 _lib = None
+_libs = {}
 
 
 class SmcmcError(RuntimeError):
@@ -112,18 +113,31 @@ class SmcmcError(RuntimeError):
         self.status = status
 
 
-def load():
-    """Load the in-tree HIP library.  Raises if it has not been built."""
+def _bind(path):
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError if the library lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+def load(path=None):
+    """Load the in-tree HIP library (or, with `path`, a build of it that carries a user likelihood:
+    `build.py --user-likelihood`).  Raises if it has not been built."""
     global _lib
+    if path is not None:
+        path = os.path.abspath(path)
+        if path not in _libs:
+            if not os.path.exists(path):
+                raise ImportError(f"{path} is missing: build it with `python root-simple-mcmc_amd/build.py "
+                                  "--user-likelihood <header>`.  There is no CPU fallback.")
+            _libs[path] = _bind(path)
+        return _libs[path]
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise ImportError(
                 f"{LIB_PATH} is missing: build it with `python root-simple-mcmc_amd/build.py` "
                 "(or __graft_entry__.build()).  There is no CPU fallback.")
-        lib = C.CDLL(LIB_PATH)
-        for name, (res, args) in SIGNATURES.items():
-            fn = getattr(lib, name)   # AttributeError if the library lacks a declared symbol
-            fn.restype = res
-            fn.argtypes = args
-        _lib = lib
+        _lib = _bind(LIB_PATH)
     return _lib

@@ -41,8 +41,11 @@ def _headers():
     return sorted(hs)
 
 
-def _units():
-    units = [("smcmc_engine.hip", [], "engine"), ("smcmc_selftest.hip", [], "selftest"),
+def _units(user_flag=None):
+    """(source, defines, object name).  With a user likelihood only the engine and the SMCMC_LIKE_USER
+    instances are compiled with it; every other object is shared with the plain build."""
+    engine = ("smcmc_engine.hip", [user_flag], "engine_user") if user_flag else ("smcmc_engine.hip", [], "engine")
+    units = [engine, ("smcmc_selftest.hip", [], "selftest"),
              ("smcmc_hmc_engine.hip", [], "hmc_engine"), ("smcmc_hmc_mfma_inst.hip", [], "hmc_mfma"),
              ("smcmc_panel_mfma_inst.hip", [], "panel_mfma")]
     for dp in dp_list():
@@ -51,13 +54,20 @@ def _units():
     for w in (4, 8):
         units.append(("smcmc_panel_inst.hip", [f"-DSMCMC_PANEL_W={w}"], f"panel_w{w}"))
         units.append(("smcmc_hmc_inst.hip", [f"-DSMCMC_PANEL_W={w}"], f"hmc_w{w}"))
+    if user_flag:
+        for dp in dp_list():   # SMCMC_LIKE_USER = 3
+            units.append(("smcmc_inst.hip", [f"-DSMCMC_DP={dp}", "-DSMCMC_LIKE=3", user_flag], f"inst_dp{dp}_l3"))
     return units
+
+
+_EXTRA = {"files": []}   # the user likelihood header, part of the stamps of the units built with it
 
 
 def _stamp(src, defs):
     h = hashlib.sha256()
     h.update(" ".join(FLAGS + defs).encode())
-    for path in [os.path.join(CSRC, src)] + _headers():
+    extra = _EXTRA["files"] if any("SMCMC_USER_LIKELIHOOD" in d for d in defs) else []
+    for path in [os.path.join(CSRC, src)] + _headers() + extra:
         h.update(path.encode())
         h.update(open(path, "rb").read())
     return h.hexdigest()
@@ -79,11 +89,24 @@ def _compile(unit):
     return obj, True
 
 
-def build(jobs=None, verbose=False):
-    """Compile every HIP translation unit for gfx950 and link the shared library."""
+def build(jobs=None, verbose=False, user_likelihood=None, output=None):
+    """Compile every HIP translation unit for gfx950 and link the shared library.
+
+    user_likelihood: a header defining smcmc_user_loglike<DP> (see smcmc_kernels.hip.h and
+    examples/user_likelihood_asym.hip.h); the library built with it (default
+    lib/libsmcmc_amd_user.so, or `output`) additionally serves SMCMC_LIKE_USER."""
+    lib_path = LIB_PATH
+    user_flag = None
+    if user_likelihood:
+        user_likelihood = os.path.abspath(user_likelihood)
+        user_flag = f'-DSMCMC_USER_LIKELIHOOD="{user_likelihood}"'
+        _EXTRA["files"] = [user_likelihood]
+        lib_path = output or os.path.join(LIB_DIR, "libsmcmc_amd_user.so")
+    else:
+        _EXTRA["files"] = []
     os.makedirs(OBJ_DIR, exist_ok=True)
     os.makedirs(LIB_DIR, exist_ok=True)
-    units = _units()
+    units = _units(user_flag)
     jobs = jobs or min(8, os.cpu_count() or 1)
     objs, rebuilt = [], 0
     with concurrent.futures.ThreadPoolExecutor(max_workers=jobs) as pool:
@@ -92,13 +115,18 @@ def build(jobs=None, verbose=False):
             rebuilt += int(did)
             if verbose and did:
                 print("built", os.path.basename(obj), flush=True)
-    if rebuilt or not os.path.exists(LIB_PATH):
-        cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc"] + objs + ["-o", LIB_PATH]
+    if rebuilt or not os.path.exists(lib_path):
+        cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc"] + objs + ["-o", lib_path]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
-    return LIB_PATH
+    return lib_path
 
 
 if __name__ == "__main__":
-    print(build(verbose=True))
+    import argparse
+    ap = argparse.ArgumentParser(description=__doc__)
+    ap.add_argument("--user-likelihood", help="header defining smcmc_user_loglike<DP>: build a library that serves SMCMC_LIKE_USER")
+    ap.add_argument("--output", help="path of the library built with --user-likelihood")
+    a = ap.parse_args()
+    print(build(verbose=True, user_likelihood=a.user_likelihood, output=a.output))

@@ -228,6 +228,15 @@ int upload_like(smcmc_engine* h) {
             for (int j = 0; j < D; ++j) et[(size_t)i * D + j] = h->like_params[(size_t)j * D + i];
         return upload_padded(h, et.data(), h->d_like);
     }
+    if (h->likelihood == SMCMC_LIKE_USER) {
+        if (h->like_params.size() > (size_t)h->dp * h->dp)
+            return fail(h, SMCMC_ERR_INVALID, "a user likelihood takes at most dim_padded^2 parameters");
+        if (!h->like_params.empty())
+            HIP_TRY(h, hipMemcpyAsync(h->d_like, h->like_params.data(), h->like_params.size() * sizeof(double),
+                                      hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        return SMCMC_OK;
+    }
     double b = 100.0;   // ROSEN_B, THardLogLikelihood.H:53
     if (h->likelihood == SMCMC_LIKE_ROSENBROCK && !h->like_params.empty()) b = h->like_params[0];
     HIP_TRY(h, hipMemcpyAsync(h->d_like, &b, sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -393,7 +402,10 @@ int smcmc_create(int dim, int nchains, int likelihood, uint64_t seed, uint32_t c
     if (!out) return SMCMC_ERR_INVALID;
     *out = nullptr;
     if (dim < 1 || nchains < 1) return SMCMC_ERR_INVALID;
-    if (likelihood < SMCMC_LIKE_ISO_GAUSS || likelihood > SMCMC_LIKE_ROSENBROCK) return SMCMC_ERR_INVALID;
+    if (likelihood < SMCMC_LIKE_ISO_GAUSS || likelihood > SMCMC_LIKE_USER) return SMCMC_ERR_INVALID;
+#ifndef SMCMC_USER_LIKELIHOOD
+    if (likelihood == SMCMC_LIKE_USER) return SMCMC_ERR_UNSUPPORTED;   // this build carries no user likelihood
+#endif
     if (likelihood == SMCMC_LIKE_ROSENBROCK && dim < 2) return SMCMC_ERR_INVALID;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return SMCMC_ERR_NO_DEVICE;
@@ -405,6 +417,7 @@ int smcmc_create(int dim, int nchains, int likelihood, uint64_t seed, uint32_t c
         if (dim <= 4 * kPanelCW) panel_w = 4;
         else if (dim <= 8 * kPanelCW) panel_w = 8;
         else return SMCMC_ERR_UNSUPPORTED;
+        if (likelihood == SMCMC_LIKE_USER) return SMCMC_ERR_UNSUPPORTED;   // user likelihoods: dim <= 63
         dp = dim;   // QUADFORM here runs in the fused order only (checked at Start)
     }
     smcmc_engine* h = new (std::nothrow) smcmc_engine();

@@ -188,6 +188,16 @@ struct StepParams {
 __device__ __forceinline__ double dmin(double a, double b) { return __builtin_fmin(a, b); }
 __device__ __forceinline__ double dmax(double a, double b) { return __builtin_fmax(a, b); }
 
+// A user likelihood compiled into the library (SMCMC_LIKE_USER): the header named by
+// SMCMC_USER_LIKELIHOOD defines
+//     template <int DP> __device__ double smcmc_user_loglike(const double (&p)[DP], smcmc::cptr_f64 params, int D);
+// p[0..D) is the point (entries past D are zero), params what smcmc_set_likelihood_params handed over.
+#ifdef SMCMC_USER_LIKELIHOOD
+}  // namespace smcmc
+#include SMCMC_USER_LIKELIHOOD
+namespace smcmc {
+#endif
+
 // log-likelihood of the point p[0..D) held in registers.
 template <int DP, int LIKE, bool EXACT>
 __device__ __forceinline__ double loglike(const double (&p)[DP], cptr_f64 prm, int D) {
@@ -221,6 +231,10 @@ __device__ __forceinline__ double loglike(const double (&p)[DP], cptr_f64 prm, i
                 }
             }
         }
+    } else if constexpr (LIKE == SMCMC_LIKE_USER) {
+#ifdef SMCMC_USER_LIKELIHOOD
+        logl = smcmc_user_loglike<DP>(p, prm, D);
+#endif
     } else {
         // THardLogLikelihood.H:60-64
         const double rb = prm[0];
@@ -691,6 +705,9 @@ inline hipError_t launch_step(const StepParams& p, int like, bool exact, bool fu
         case SMCMC_LIKE_ISO_GAUSS: return launch_step_like<DP, SMCMC_LIKE_ISO_GAUSS>(p, exact, fullu, moments, special, stream);
         case SMCMC_LIKE_QUADFORM: return launch_step_like<DP, SMCMC_LIKE_QUADFORM>(p, exact, fullu, moments, special, stream);
         case SMCMC_LIKE_ROSENBROCK: return launch_step_like<DP, SMCMC_LIKE_ROSENBROCK>(p, exact, fullu, moments, special, stream);
+#ifdef SMCMC_USER_LIKELIHOOD
+        case SMCMC_LIKE_USER: return launch_step_like<DP, SMCMC_LIKE_USER>(p, exact, fullu, moments, special, stream);
+#endif
         default: return hipErrorInvalidValue;
     }
 }

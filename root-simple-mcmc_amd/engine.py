@@ -10,7 +10,8 @@ import ctypes as C
 import numpy as np
 
 from . import _capi
-from ._capi import (LIKE_ISO_GAUSS, LIKE_QUADFORM, LIKE_ROSENBROCK, MODE_FROZEN, MODE_POOLED, P, SmcmcError)
+from ._capi import (LIKE_ISO_GAUSS, LIKE_QUADFORM, LIKE_ROSENBROCK, LIKE_USER, MODE_FROZEN, MODE_POOLED, P,  # noqa: F401
+                    SmcmcError)
 
 _dp = C.POINTER(C.c_double)
 
@@ -27,8 +28,9 @@ class Engine:
     """N chains of dimension D advancing in lock step on one GPU."""
 
     def __init__(self, dim, nchains=1, likelihood=LIKE_ISO_GAUSS, likelihood_params=None, seed=20240607,
-                 chain_offset=0, device=0, mode=MODE_POOLED, exact=True, stream=None):
-        self._lib = _capi.load()
+                 chain_offset=0, device=0, mode=MODE_POOLED, exact=True, stream=None, library=None):
+        # library: path of a build that carries a user likelihood (LIKE_USER), see build.py --user-likelihood
+        self._lib = _capi.load(library)
         self.dim, self.nchains = int(dim), int(nchains)
         h = C.c_void_p()
         st = self._lib.smcmc_create(self.dim, self.nchains, likelihood, seed, chain_offset, device, C.byref(h))

@@ -1,0 +1,68 @@
+"""A user likelihood compiled into the library (SMCMC_LIKE_USER; build.py --user-likelihood): the
+reference's TASymLogLikelihood (TAsymLogLikelihood.H:20-31) as examples/user_likelihood_asym.hip.h."""
+import os
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+USER_LIB = os.path.join(ROOT, "root-simple-mcmc_amd", "lib", "libsmcmc_amd_user.so")
+HEADER = os.path.join(ROOT, "examples", "user_likelihood_asym.hip.h")
+
+
+def _user_lib(smcmc):
+    """The example library: built by __graft_entry__.build(); rebuilt here only if it is missing."""
+    if not os.path.exists(USER_LIB):
+        smcmc._build_mod.build(user_likelihood=HEADER)
+    return USER_LIB
+
+
+def test_user_library_exports_the_whole_c_abi(smcmc):
+    lib = smcmc.load(_user_lib(smcmc))
+    for name in smcmc.SIGNATURES:
+        assert hasattr(lib, name)
+
+
+def test_plain_build_refuses_a_user_likelihood(smcmc):
+    import ctypes as C
+    h = C.c_void_p()
+    st = smcmc.load().smcmc_create(5, 8, smcmc.LIKE_USER, 1, 0, 0, C.byref(h))
+    assert st == 5               # SMCMC_ERR_UNSUPPORTED, before any device is looked for
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["frozen", "pooled"])
+def test_asymmetric_user_likelihood_runs_in_the_step_kernel(gpu, mode):
+    dim, n = 10, 2048
+    slopes = np.array([-1.0, 100.0])
+    e = gpu.Engine(dim, n, likelihood=gpu.LIKE_USER, likelihood_params=slopes, library=_user_lib(gpu),
+                   mode=gpu.MODE_FROZEN if mode == "frozen" else gpu.MODE_POOLED, seed=5)
+    assert e.Start(np.full(dim, 0.5))
+    for _ in range(15):
+        e.Step(200)
+        if mode == "pooled":
+            e.sync()
+    x, logl = e.GetAccepted(), e.GetAcceptedLogLikelihood()
+    # the stored likelihood is the function of the stored point, bit for bit (same operation order)
+    ref = np.zeros(n)
+    for i in range(dim):
+        a = x[i].copy()
+        neg = a < 0.0
+        a[neg] *= slopes[1]
+        a[~neg] *= slopes[0]
+        ref += a
+    assert np.array_equal(logl, ref)
+    # p(x) ~ exp(-x) above zero, exp(100 x) below: mean 1 - 0.01 + O(1e-4) per dimension, almost no mass below zero
+    assert abs(x.mean() - 0.99) < 0.06
+    assert (x < -0.1).mean() < 1e-3
+    assert 0.1 < e.lane("naccept").sum() / (n * 3000) < 0.6
+
+
+@pytest.mark.gpu
+def test_user_likelihood_limits(gpu):
+    with pytest.raises(gpu.SmcmcError) as err:
+        gpu.Engine(100, 64, likelihood=gpu.LIKE_USER, library=_user_lib(gpu))      # dim <= 63 only
+    assert err.value.status == 5
+    with pytest.raises(gpu.SmcmcError) as err:
+        gpu.Engine(5, 64, likelihood=gpu.LIKE_USER)                                 # the plain library has none
+    assert err.value.status == 5

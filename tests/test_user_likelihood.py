@@ -66,3 +66,20 @@ def test_user_likelihood_limits(gpu):
     with pytest.raises(gpu.SmcmcError) as err:
         gpu.Engine(5, 64, likelihood=gpu.LIKE_USER)                                 # the plain library has none
     assert err.value.status == 5
+
+
+@pytest.mark.gpu
+def test_cpp_host_with_a_user_likelihood(gpu, tmp_path):
+    """examples/UserLikelihood_amd.C: TSimpleMCMC<TASymLogLikelihood> linked against the user library; the device's
+    log-likelihood of the accepted point equals the host functor's, bit for bit."""
+    import subprocess
+    _user_lib(gpu)
+    libdir = os.path.dirname(USER_LIB)
+    exe = str(tmp_path / "user_amd.exe")
+    r = subprocess.run(["g++", "-std=c++17", "-O2", "-Wall", "-Werror", f"-I{os.path.join(ROOT, 'include')}",
+                        os.path.join(ROOT, "examples", "UserLikelihood_amd.C"), f"-L{libdir}", "-lsmcmc_amd_user",
+                        f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([exe, "512"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "(identical)" in r.stdout

@@ -23,6 +23,7 @@ struct smcmc_hmc {
     bool started = false;
     bool exact = true;             // false: fused order, the quadratic-form gradient on the matrix pipe
     bool use_mfma = false;
+    bool use_matrix_exact = false;   // quadratic form, reference order: the matrix layout on the vector pipe
     double alpha = 0.0;            // fAlpha, TSimpleHMC.H:133
     double mean_epsilon = 0.05;    // fMeanEpsilon, set by Start (:229)
     int leapfrog = 10;             // fLeapFrogSteps (:133); SetLeapFrog(n) stores -n (:190)
@@ -64,6 +65,7 @@ HmcParams hmc_params(smcmc_hmc* h, int nsteps, int init_only) {
 
 hipError_t hmc_dispatch(smcmc_hmc* h, const HmcParams& p) {
     if (h->use_mfma) return launch_hmc_mfma(p, h->stream);
+    if (h->use_matrix_exact) return launch_hmc_matrix_exact(p, h->stream);
     return (h->W == 4) ? launch_hmc<4, kPanelCW>(p, h->likelihood, h->stream)
                        : launch_hmc<8, kPanelCW>(p, h->likelihood, h->stream);
 }
@@ -96,7 +98,7 @@ int smcmc_hmc_create(int dim, int nchains, int likelihood, uint64_t seed, uint32
     HMC_TRY(h, hipMalloc(&h->d_pm, vec));
     HMC_TRY(h, hipMalloc(&h->d_qn, vec));
     HMC_TRY(h, hipMalloc(&h->d_pn, vec));
-    const size_t e_doubles = std::max((size_t)h->W * dim * kPanelCW, hmc_mfma_eop_doubles(dim));
+    const size_t e_doubles = std::max({(size_t)h->W * dim * kPanelCW, hmc_mfma_eop_doubles(dim), hmc_exact_ex_doubles(dim)});
     HMC_TRY(h, hipMalloc(&h->d_E, sizeof(double) * e_doubles));
     HMC_TRY(h, hipMalloc(&h->d_like, sizeof(double) * 8));
     HMC_TRY(h, hipMalloc(&h->d_lane_f64, sizeof(double) * (size_t)h->npad * SMCMC_LANE_F64_COUNT_));
@@ -158,6 +160,21 @@ int smcmc_hmc_start(smcmc_hmc* h, const double* x0, int broadcast) {
         if ((int)h->like_params.size() != D * D)
             return hfail(h, SMCMC_ERR_INVALID, "QUADFORM needs dim*dim likelihood parameters (the Error matrix)");
         h->use_mfma = !h->exact && D <= kMfDimMax;
+        h->use_matrix_exact = h->exact && D <= kMfDimMax;
+        if (h->use_matrix_exact) {
+            // Ex[(tile * D + j) * 16 + 4 rq + r] = Error(16 tile + 4 r + rq, j)
+            const int ntiles = (D + 15) / 16;
+            std::vector<double> ex(hmc_exact_ex_doubles(D), 0.0);
+            for (int it = 0; it < ntiles; ++it)
+                for (int j = 0; j < D; ++j)
+                    for (int rq = 0; rq < 4; ++rq)
+                        for (int r = 0; r < 4; ++r) {
+                            const int i = 16 * it + 4 * r + rq;
+                            if (i < D) ex[((size_t)it * D + j) * 16 + 4 * rq + r] = h->like_params[(size_t)i * D + j];
+                        }
+            HMC_TRY(h, hipMemcpyAsync(h->d_E, ex.data(), ex.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+            HMC_TRY(h, hipStreamSynchronize(h->stream));
+        }
         if (h->use_mfma) {
             // Eop[(tile * nkq + kq) * 64 + lane] = Error(16 tile + (lane & 15), 4 kq + (lane >> 4)): the A operand
             // of every matrix instruction as one contiguous 512-byte read
@@ -180,12 +197,13 @@ int smcmc_hmc_start(smcmc_hmc* h, const double* x0, int broadcast) {
                     const int i = il * W + w;
                     if (i < D) perm[((size_t)w * D + j) * kPanelCW + il] = h->like_params[(size_t)i * D + j];
                 }
-        if (!h->use_mfma) {
+        if (!h->use_mfma && !h->use_matrix_exact) {
             HMC_TRY(h, hipMemcpyAsync(h->d_E, perm.data(), perm.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
             HMC_TRY(h, hipStreamSynchronize(h->stream));
         }
     } else {
         h->use_mfma = false;
+        h->use_matrix_exact = false;
     }
     double b = 100.0;
     if (h->likelihood == SMCMC_LIKE_ROSENBROCK && !h->like_params.empty()) b = h->like_params[0];

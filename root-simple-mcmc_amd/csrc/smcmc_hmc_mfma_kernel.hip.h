@@ -42,8 +42,14 @@ constexpr int kMfDimMax = 16 * kMfW * kMfTIMax;
 // (k-quads per tile rounded up to the prefetch depth of pm_contract, zero padded)
 inline size_t hmc_mfma_eop_doubles(int dim) { return panel_mfma_uop_doubles(dim); }
 
-// TI = 16-component tiles a wavefront owns: dim <= 128 TI
-template <int kMfTI>
+// Ex[(tile * dim + j) * 16 + 4 rq + r] = Error(16 tile + 4 r + rq, j): column j of a tile's sixteen rows in the
+// order the matrix layout holds them (lane quarter rq, register r), one 32-byte read per lane
+inline size_t hmc_exact_ex_doubles(int dim) { return (size_t)((dim + 15) / 16) * dim * 16; }
+
+// TI = 16-component tiles a wavefront owns: dim <= 128 TI.
+// FUSED = false: the reference's order, g[i] -= Error(i,j) * q[j] as an un-fused multiply and subtract, j
+// ascending (TDummyLogLikelihood.H:34-42), on the vector pipe in the same layout (p.Eperm = Ex).
+template <int kMfTI, bool FUSED = true>
 __global__ void __launch_bounds__(kMfW* kWave, 1) hmc_mfma_kernel(const HmcParams p) {
     __shared__ double qs[16 * kMfW * kMfTI * kMfCT];   // [component][chain]: the published vector
     __shared__ int verdict[kMfCT];
@@ -100,11 +106,41 @@ __global__ void __launch_bounds__(kMfW* kWave, 1) hmc_mfma_kernel(const HmcParam
         for (int t = 0; t < kMfTI; ++t)
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct) gr[t][ct] = f64x4v{0.0, 0.0, 0.0, 0.0};
-        const double* qs_lane = qs + rq * kMfCT + c;
+        if constexpr (FUSED) {
+            const double* qs_lane = qs + rq * kMfCT + c;
 #pragma unroll
-        for (int t = 0; t < kMfTI; ++t) {
-            if (!owns(t)) continue;
-            pm_contract(p.Eperm + lane + (size_t)(t * kMfW + w) * nkqp * 64, qs_lane, nkqp, gr[t][0], gr[t][1]);
+            for (int t = 0; t < kMfTI; ++t) {
+                if (!owns(t)) continue;
+                pm_contract(p.Eperm + lane + (size_t)(t * kMfW + w) * nkqp * 64, qs_lane, nkqp, gr[t][0], gr[t][1]);
+            }
+        } else {
+            const double* ex = p.Eperm + 4 * rq;
+            const double* qv = qs + c;
+            f64x4v en[kMfTI];   // column j + 1 of Error is fetched while column j is consumed
+#pragma unroll
+            for (int t = 0; t < kMfTI; ++t)
+                en[t] = owns(t) ? *(const f64x4v*)(ex + ((size_t)(t * kMfW + w) * D) * 16) : f64x4v{0.0, 0.0, 0.0, 0.0};
+            for (int j = 0; j < D; ++j) {
+                const double q0 = qv[j * kMfCT], q1 = qv[j * kMfCT + 16];
+                f64x4v e[kMfTI];
+#pragma unroll
+                for (int t = 0; t < kMfTI; ++t) {
+                    e[t] = en[t];
+                    if (owns(t) && j + 1 < D) en[t] = *(const f64x4v*)(ex + ((size_t)(t * kMfW + w) * D + j + 1) * 16);
+                }
+#pragma unroll
+                for (int t = 0; t < kMfTI; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        gr[t][0][r] -= e[t][r] * q0;
+                        gr[t][1][r] -= e[t][r] * q1;
+                    }
+            }
+#pragma unroll
+            for (int t = 0; t < kMfTI; ++t) {   // TSimpleHMC.H:486: the potential's gradient is -grad(log L)
+                gr[t][0] = -gr[t][0];
+                gr[t][1] = -gr[t][1];
+            }
         }
         __syncthreads();   // the positions may be overwritten again
     };
@@ -318,5 +354,6 @@ __global__ void __launch_bounds__(kMfW* kWave, 1) hmc_mfma_kernel(const HmcParam
 }
 
 hipError_t launch_hmc_mfma(const HmcParams& p, hipStream_t stream);
+hipError_t launch_hmc_matrix_exact(const HmcParams& p, hipStream_t stream);
 
 }  // namespace smcmc

@@ -89,38 +89,54 @@ def _compile(unit):
     return obj, True
 
 
-def build(jobs=None, verbose=False, user_likelihood=None, output=None):
+def _link(objs, lib_path):
+    cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc"] + objs + ["-o", lib_path]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+
+
+def build(jobs=None, verbose=False, user_likelihood=None, output=None, with_plain=False):
     """Compile every HIP translation unit for gfx950 and link the shared library.
 
     user_likelihood: a header defining smcmc_user_loglike<DP> (see smcmc_kernels.hip.h and
     examples/user_likelihood_asym.hip.h); the library built with it (default
-    lib/libsmcmc_amd_user.so, or `output`) additionally serves SMCMC_LIKE_USER."""
-    lib_path = LIB_PATH
-    user_flag = None
+    lib/libsmcmc_amd_user.so, or `output`) additionally serves SMCMC_LIKE_USER.  with_plain: also
+    (re)build lib/libsmcmc_amd.so in the same pass, all units in one pool."""
+    user_flag, user_lib = None, None
     if user_likelihood:
         user_likelihood = os.path.abspath(user_likelihood)
         user_flag = f'-DSMCMC_USER_LIKELIHOOD="{user_likelihood}"'
         _EXTRA["files"] = [user_likelihood]
-        lib_path = output or os.path.join(LIB_DIR, "libsmcmc_amd_user.so")
+        user_lib = output or os.path.join(LIB_DIR, "libsmcmc_amd_user.so")
     else:
         _EXTRA["files"] = []
     os.makedirs(OBJ_DIR, exist_ok=True)
     os.makedirs(LIB_DIR, exist_ok=True)
-    units = _units(user_flag)
+    plain_units = _units(None)
+    user_units = _units(user_flag) if user_flag else []
+    want_plain = with_plain or not user_flag
+    todo, seen = [], set()
+    for u in (plain_units if want_plain else []) + user_units:
+        if u[2] not in seen:
+            seen.add(u[2])
+            todo.append(u)
     jobs = jobs or min(8, os.cpu_count() or 1)
-    objs, rebuilt = [], 0
+    built = {}
     with concurrent.futures.ThreadPoolExecutor(max_workers=jobs) as pool:
-        for obj, did in pool.map(_compile, units):
-            objs.append(obj)
-            rebuilt += int(did)
+        for unit, (obj, did) in zip(todo, pool.map(_compile, todo)):
+            built[unit[2]] = (obj, did)
             if verbose and did:
                 print("built", os.path.basename(obj), flush=True)
-    if rebuilt or not os.path.exists(lib_path):
-        cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc"] + objs + ["-o", lib_path]
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        if r.returncode != 0:
-            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
-    return lib_path
+    result = None
+    for units, lib_path in ((plain_units if want_plain else None, LIB_PATH), (user_units or None, user_lib)):
+        if not units:
+            continue
+        objs = [built[u[2]][0] for u in units]
+        if any(built[u[2]][1] for u in units) or not os.path.exists(lib_path):
+            _link(objs, lib_path)
+        result = lib_path
+    return result
 
 
 if __name__ == "__main__":

@@ -93,6 +93,9 @@ def main():
     ap.add_argument("--no-ess", action="store_true", help="skip the ESS trace after the timed region")
     ap.add_argument("--frozen", action="store_true", help="diagnostic: frozen covariance, no moment fold")
     ap.add_argument("--dim", type=int, default=DIM, help="diagnostic: other dimension (not the headline)")
+    ap.add_argument("--header-tdummy", action="store_true",
+                    help="the other C2 likelihood of SURVEY.md 8(d): header-form TDummyLogLikelihood (quadratic form, Error "
+                         "from Init(), correlation 0.999999 between the first and last coordinate); not the headline")
     args = ap.parse_args()
 
     import torch
@@ -113,7 +116,13 @@ def main():
 
     stream = torch.cuda.current_stream()
     dim = args.dim
-    eng = pkg.Engine(dim, args.chains, likelihood=pkg.LIKE_ISO_GAUSS, seed=20240607,
+    like, like_params = pkg.LIKE_ISO_GAUSS, None
+    if args.header_tdummy:
+        # TDummyLogLikelihood::Init() (TDummyLogLikelihood.H:44-142): identity covariance except the (0, D-1) pair
+        cov = np.eye(dim)
+        cov[0, dim - 1] = cov[dim - 1, 0] = 0.999999
+        like, like_params = pkg.LIKE_QUADFORM, np.linalg.inv(cov)
+    eng = pkg.Engine(dim, args.chains, likelihood=like, likelihood_params=like_params, seed=20240607,
                      chain_offset=rank * args.chains, device=local,
                      mode=pkg.MODE_FROZEN if args.frozen else pkg.MODE_POOLED,
                      exact=not args.fast, stream=stream.cuda_stream)
@@ -191,8 +200,10 @@ def main():
         "value": value, "unit": "chain-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "TDummyLogLikelihood README form (iso-Gaussian) D=50, 65536 chains/GPU, "
-                               "TProposeAdaptiveStep pooled covariance, window=%d steps/launch" % args.window,
+        "config": {"workload": ("TDummyLogLikelihood header form (quadratic form)" if args.header_tdummy else
+                                "TDummyLogLikelihood README form (iso-Gaussian)") +
+                               " D=%d, %d chains/GPU, TProposeAdaptiveStep pooled covariance, window=%d steps/launch"
+                               % (dim, args.chains, args.window),
                    "dim": dim, "mode": "frozen" if args.frozen else "pooled", "chains_per_gpu": args.chains, "window": args.window,
                    "arithmetic": "fused" if args.fast else "reference-order", "seed": 20240607},
         "accept_rate": float(naccept.sum() / (total_steps * args.chains)),
@@ -203,7 +214,8 @@ def main():
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                      "traffic_unit": "bytes per launch (2 x FETCH_SIZE + WRITE_SIZE)",
                      "algorithmic_bytes_per_launch": per_launch * bytes_cs,
-                     "kernel": "step_kernel<50,ISO,%s,tri,moments>" % ("fused" if args.fast else "exact"),
+                     "kernel": "step_kernel<%d,%s,%s,tri,moments>" % (dim, "QUADFORM" if args.header_tdummy else "ISO",
+                                                                           "fused" if args.fast else "exact"),
                      "kernel_ms": kms, "bytes_per_chain_step": bytes_cs,
                      "chain_steps_per_launch": per_launch},
     }

@@ -114,3 +114,32 @@ def test_sharded_oracle_equals_whole_in_frozen_mode(oracle):
     whole = oracle.Ensemble(n, dim, mode=oracle.MODE_FROZEN); whole.start(np.zeros(dim)); whole.step(200)
     hi = oracle.Ensemble(n // 2, dim, chain_offset=n // 2, mode=oracle.MODE_FROZEN); hi.start(np.zeros(dim)); hi.step(200)
     assert np.array_equal(whole.x[:, n // 2:], hi.x)
+
+
+def test_posterior_moments_accumulator_algebra(oracle, smcmc):
+    """PosteriorMoments (the posterior mean/covariance reducer over the pooled moment sums) re-centres every
+    window's sums correctly: checked against the plain sample moments of every visited point, with the CPU
+    ensemble standing in for the engine."""
+    dim, n, window = 4, 64, 25
+    e = oracle.Ensemble(n, dim, seed=3)
+    assert e.start(np.full(dim, 0.2))
+
+    class Adapter:                      # the two calls PosteriorMoments makes on an engine
+        def __init__(self): self.m = None
+        def read_moments(self): return self.m
+        def GetEstimatedCenter(self): return e.center
+
+    ad = Adapter()
+    acc = smcmc.PosteriorMoments(dim)
+    xs = []
+    for w in range(6):
+        for _ in range(window):
+            xs.append(e.x.copy())       # the point every chain holds at the start of the step is what gets folded
+            e.step(1)
+        ad.m = e.reduce_moments()
+        acc.add(ad)                     # before apply_moments: the centre is still the window's c0
+        e.apply_moments(ad.m)
+    pts = np.concatenate(xs, axis=1)    # [dim][steps * chains]
+    assert acc.n == pts.shape[1]
+    assert np.allclose(acc.mean, pts.mean(axis=1), rtol=1e-12, atol=1e-14)
+    assert np.allclose(acc.covariance, np.cov(pts, bias=True), rtol=1e-10, atol=1e-13)

@@ -259,6 +259,28 @@ __device__ __forceinline__ double loglike(const double (&p)[DP], cptr_f64 prm, i
 
 // SPECIAL = the variant that also knows uniform per-dimension proposals and the scan of one
 // dimension (TSimpleMCMC.H:685-716); kept out of the common kernels, whose register allocation it disturbs.
+// The quadratic form (TDummyLogLikelihood.H:24-28) of a point held in a column of LDS, xq[j * kXStride]:
+// the D^2-term running sum needs every p[j] for every i, which a register array can only give to fully
+// unrolled code (50 x 50 terms: minutes of compile time per kernel) -- a rolled outer loop indexes it
+// dynamically and the compiler moves it to scratch memory.  From LDS the outer loop can stay rolled.
+template <int DP, bool EXACT>
+__device__ __forceinline__ double loglike_quadform_lds(const double* xq, cptr_f64 prm) {
+    double logl = 0.0;
+#pragma nounroll
+    for (int i = 0; i < DP; ++i) {
+        const double h = 0.5 * xq[i * kXStride];
+        cptr_f64 ep = prm + i * DP;
+#pragma unroll
+        for (int j = 0; j < DP; ++j) {
+            const double e = ep[j];
+            const double pj = xq[j * kXStride];
+            if constexpr (EXACT) logl -= h * e * pj;
+            else logl = SMCMC_FMA(-(h * e), pj, logl);
+        }
+    }
+    return logl;
+}
+
 template <int DP, int LIKE, bool EXACT, bool FULLU, bool MOMENTS, bool SPECIAL>
 __global__ void __launch_bounds__(kWave, 2) step_kernel(const StepParams p) {
     constexpr int T = Geo<DP>::T;
@@ -359,11 +381,22 @@ __global__ void __launch_bounds__(kWave, 2) step_kernel(const StepParams p) {
     // StepRMS window, likelihood, Metropolis test and accept copy of one step
     // (TSimpleMCMC.H:391-406, 410-491) for the proposal held in xp.
     auto finish_step = [&](int s, uint32_t uword) {
+        // QUADFORM: the proposal and the accepted point trade places -- the likelihood reads the proposal from
+        // the LDS column, the registers keep the accepted point to put back on a reject
+        constexpr bool SWAP = (LIKE == SMCMC_LIKE_QUADFORM);
+        if constexpr (SWAP) {
+#pragma unroll
+            for (int d = 0; d < DP; ++d) {
+                const double t = xcol[d * kXStride];
+                xcol[d * kXStride] = xp[d];
+                xp[d] = t;
+            }
+        }
         if (p.step_rms_window > 0) {
             double sqr = 0.0;
 #pragma unroll
             for (int d = 0; d < DP; ++d) {
-                double t = xp[d] - xcol[d * kXStride];
+                double t = SWAP ? xcol[d * kXStride] - xp[d] : xp[d] - xcol[d * kXStride];
                 if constexpr (EXACT) sqr += t * t;
                 else sqr = SMCMC_FMA(t, t, sqr);
             }
@@ -374,7 +407,8 @@ __global__ void __launch_bounds__(kWave, 2) step_kernel(const StepParams p) {
             rms_trials = (p.step_rms_window < rms_trials + 1) ? p.step_rms_window : rms_trials + 1;
             step_rms = __builtin_sqrt(ms);
         }
-        logl_prop = loglike<DP, LIKE, EXACT>(xp, likep + p.zero * (s + 1), D);
+        if constexpr (SWAP) logl_prop = loglike_quadform_lds<DP, EXACT>(xcol, likep + p.zero * (s + 1));
+        else logl_prop = loglike<DP, LIKE, EXACT>(xp, likep + p.zero * (s + 1), D);
         bool take;
         if (p.metropolis == 2) {
             take = true;
@@ -396,6 +430,8 @@ __global__ void __launch_bounds__(kWave, 2) step_kernel(const StepParams p) {
         if (take) {
             logl = logl_prop;
             ++naccept;
+        }
+        if (take != SWAP) {   // plain: commit the proposal on accept; swapped: put the accepted point back on reject
 #pragma unroll
             for (int d = 0; d < DP; ++d) xcol[d * kXStride] = xp[d];
         }

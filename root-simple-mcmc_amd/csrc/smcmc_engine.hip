@@ -317,6 +317,7 @@ int launch(smcmc_engine* h, int nsteps, int metropolis, int stride, double* save
         q.step_rms_window = p.step_rms_window; q.full_u = h->prop->decompFull ? 1 : 0;
         q.x = p.x; q.lane_f64 = p.lane_f64; q.lane_i32 = p.lane_i32;
         q.save_stride = 1;
+        q.has_forced = p.has_forced; q.forced = p.forced;
         const bool exact = h->exact || h->prop->decompFull;
         if (exact && h->likelihood == SMCMC_LIKE_QUADFORM)
             return fail(h, SMCMC_ERR_UNSUPPORTED, "the quadratic-form likelihood for dim > 63 runs in the fused order only");
@@ -330,13 +331,14 @@ int launch(smcmc_engine* h, int nsteps, int metropolis, int stride, double* save
             int seg = nsteps - done;
             if (pooled) {
                 const int phase = (int)(h->total_steps % (uint32_t)h->moment_stride);
-                if (phase == 0) {
+                if (phase == 0 && !q.has_forced) {   // a forced step does not call UpdateState: nothing to fold
                     hipError_t e = launch_fold(h->d_x, h->d_c0, h->nchains, h->npad, h->dim, h->slice_chains, h->fold_nslices, h->d_gacc,
                                                h->stream);
                     if (e != hipSuccess) return fail(h, SMCMC_ERR_HIP, std::string("fold kernel launch: ") + hipGetErrorString(e));
                 }
                 seg = std::min(seg, h->moment_stride - phase);
             }
+            if (q.has_forced) seg = 1;   // the forced step is a launch of its own (FORCED instantiation of the fused kernel)
             q.nsteps = seg;
             q.step0 = h->total_steps;
             hipError_t e;
@@ -353,9 +355,11 @@ int launch(smcmc_engine* h, int nsteps, int metropolis, int stride, double* save
             done += seg;
             q.pending_sigma_scale = 1.0;
             q.pending_deweight = 0;
+            q.has_forced = 0;
         }
         h->pending_sigma_scale = 1.0;
         h->pending_deweight = 0;
+        h->has_forced = false;
         return SMCMC_OK;
     }
     const bool moments = (h->mode == SMCMC_MODE_POOLED);
@@ -810,7 +814,6 @@ int smcmc_step_save(smcmc_engine* h, int nsteps, int metropolis, int stride, dou
 
 int smcmc_force_step(smcmc_engine* h, const double* point, int broadcast) {
     if (!h || !point) return SMCMC_ERR_INVALID;
-    if (h->panel_w) return fail(h, SMCMC_ERR_UNSUPPORTED, "ForceStep for dim > 63 is not on the HIP path yet");
     const int D = h->dim, N = h->nchains;
     const size_t NP = (size_t)h->npad;
     std::vector<double> x(NP * h->dp, 0.0);

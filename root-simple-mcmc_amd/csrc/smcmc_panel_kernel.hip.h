@@ -51,6 +51,8 @@ struct PanelParams {
     double* save_logl;
     int save_stride;
     int init_only;            // matrix-pipe kernel: only evaluate log L at x into LANE_LOGL (Start, :258)
+    int has_forced;           // ForceStep pending (TSimpleMCMC.H:671-678): the first step proposes `forced`
+    const double* forced;     // [dim][npad]
 };
 
 template <int W, int CW, int LIKE, bool EXACT>
@@ -106,7 +108,11 @@ __global__ void __launch_bounds__(W * kWave) panel_step_kernel(const PanelParams
     for (int s = 0; s < p.nsteps; ++s) {
         const uint64_t step = (uint64_t)(p.step0 + (uint32_t)s + 1u);
 
+        // ForceStep (TSimpleMCMC.H:671-678): the proposal is the forced point, the proposal state is not updated
+        const bool forced_now = p.has_forced && s == 0;
+
         // ---- A: UpdateState, scalar half (TSimpleMCMC.H:1723-1776), every wavefront ----
+        if (!forced_now) {
         ++trials;
         const double x0 = p.x[chain];
         const bool moved = (logl != last_value) || (x0 != last_x0);
@@ -138,15 +144,21 @@ __global__ void __launch_bounds__(W * kWave) panel_step_kernel(const PanelParams
         }
         last_value = logl;
         last_x0 = x0;
+        }
 
         // ---- B: proposal columns of this wavefront ----
+        const double* xsrc = forced_now ? p.forced : p.x;
 #pragma unroll
         for (int jl = 0; jl < CW; ++jl) {
             const int j = jl * W + w;
-            xp[jl] = (j < D) ? p.x[(size_t)j * NP + chain] : 0.0;
+            xp[jl] = (j < D) ? xsrc[(size_t)j * NP + chain] : 0.0;
         }
         uint32_t uword = 0;
-        for (int pn = 0; pn < npanels; ++pn) {
+        if (forced_now && w == 0) {
+            smcmc_u32x4 blk = smcmc_draw_block(p.seed, gid, step, aw >> 2, SMCMC_STREAM_STEP);
+            verdict_logl[lane] = smcmc_u01(smcmc_select_word(blk, aw & 3u));
+        }
+        for (int pn = 0; pn < (forced_now ? 0 : npanels); ++pn) {
             const int i0 = pn * kPanelRows;
             __syncthreads();                       // the previous panel has been consumed
             // normals of rows i0 .. i0+KP-1: Philox block b covers rows 4b..4b+3
@@ -199,7 +211,7 @@ __global__ void __launch_bounds__(W * kWave) panel_step_kernel(const PanelParams
         }
         __syncthreads();   // the U staging area is reused by the gather below
         // the Metropolis uniform when its word lies past the last row block
-        if ((aw >> 2) >= (uint32_t)(npanels * (kPanelRows / 4)) && w == 0) {
+        if (!forced_now && (aw >> 2) >= (uint32_t)(npanels * (kPanelRows / 4)) && w == 0) {
             smcmc_u32x4 blk = smcmc_draw_block(p.seed, gid, step, aw >> 2, SMCMC_STREAM_STEP);
             verdict_logl[lane] = smcmc_u01(smcmc_select_word(blk, aw & 3u));
         }

@@ -3,13 +3,20 @@
 
 namespace smcmc {
 
+template <int LIKE, bool FORCED>
+static hipError_t go_panel_mfma_f(const PanelParams& p, hipStream_t s) {
+    const dim3 grid(p.npad / kPmCT), block(kPmW * kWave);
+    if (p.dim <= 128) hipLaunchKernelGGL(HIP_KERNEL_NAME(panel_mfma_kernel<1, LIKE, FORCED>), grid, block, 0, s, p);
+    else if (p.dim <= 256) hipLaunchKernelGGL(HIP_KERNEL_NAME(panel_mfma_kernel<2, LIKE, FORCED>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(panel_mfma_kernel<4, LIKE, FORCED>), grid, block, 0, s, p);
+    return hipGetLastError();
+}
+
+// p.has_forced: the launch must be a single step (the engine cuts it so); it runs the FORCED instantiation
 template <int LIKE>
 static hipError_t go_panel_mfma(const PanelParams& p, hipStream_t s) {
-    const dim3 grid(p.npad / kPmCT), block(kPmW * kWave);
-    if (p.dim <= 128) hipLaunchKernelGGL(HIP_KERNEL_NAME(panel_mfma_kernel<1, LIKE>), grid, block, 0, s, p);
-    else if (p.dim <= 256) hipLaunchKernelGGL(HIP_KERNEL_NAME(panel_mfma_kernel<2, LIKE>), grid, block, 0, s, p);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(panel_mfma_kernel<4, LIKE>), grid, block, 0, s, p);
-    return hipGetLastError();
+    if (p.has_forced) return (p.nsteps == 1) ? go_panel_mfma_f<LIKE, true>(p, s) : hipErrorInvalidValue;
+    return go_panel_mfma_f<LIKE, false>(p, s);
 }
 
 hipError_t launch_panel_mfma(const PanelParams& p, int like, hipStream_t s) {

@@ -75,7 +75,9 @@ __device__ __forceinline__ void pm_contract(const double* __restrict__ a_ptr, co
 }
 
 // TI = 16-component tiles per wavefront: dim <= 128 TI
-template <int TI, int LIKE>
+// FORCED = the one-step instantiation that proposes the ForceStep point (kept out of the common kernel,
+// whose register allocation the extra paths disturb: 0.30 -> 0.37 ms/step at D=500)
+template <int TI, int LIKE, bool FORCED = false>
 __global__ void __launch_bounds__(kPmW* kWave, 1) panel_mfma_kernel(const PanelParams p) {
     __shared__ double qs[16 * kPmW * TI * kPmCT];   // z[i][chain], later the published values of the ordered sums
     __shared__ double sig[kPmCT], x0s[kPmCT];
@@ -203,8 +205,16 @@ __global__ void __launch_bounds__(kPmW* kWave, 1) panel_mfma_kernel(const PanelP
         const uint64_t step = (uint64_t)(p.step0 + (uint32_t)s + 1u);
         uint32_t uword = 0;
 
+        // ForceStep (TSimpleMCMC.H:671-678): the proposal is the forced point, the proposal state is not updated
+        constexpr bool forced_now = FORCED;   // the engine launches the FORCED instantiation for that one step
+        if (summer && forced_now) {
+            const uint32_t gid = p.chain_offset + (uint32_t)mychain;
+            const smcmc_u32x4 ablk = smcmc_draw_block(p.seed, gid, step, aw >> 2, SMCMC_STREAM_STEP);
+            uword = smcmc_select_word(ablk, aw & 3u);
+        }
+
         // ---- A: UpdateState, scalar half (TSimpleMCMC.H:1723-1776), one lane per chain ----
-        if (summer) {
+        if (summer && !forced_now) {
             ++trials;
             const double x0 = x0s[lane];
             const bool moved = (logl != last_value) || (x0 != last_x0);
@@ -244,7 +254,7 @@ __global__ void __launch_bounds__(kPmW* kWave, 1) panel_mfma_kernel(const PanelP
         __syncthreads();   // sigma published; the previous step's readers of qs are done
 
         // ---- B1: z = sigma r (TSimpleMCMC.H:719-722): one Philox block = four rows of one chain ----
-        {
+        if constexpr (!forced_now) {
             const int ntask = nkq * kPmCT;
             for (int task = tid; task < ntask; task += kPmW * kWave) {
                 const int b = task / kPmCT, ch = task - b * kPmCT;
@@ -262,7 +272,17 @@ __global__ void __launch_bounds__(kPmW* kWave, 1) panel_mfma_kernel(const PanelP
         __syncthreads();
 
         // ---- B2: x' = x + U^T z on the matrix pipe, rows i ascending ----
-        {
+        if constexpr (forced_now) {
+#pragma unroll
+            for (int t = 0; t < TI; ++t)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = comp(t, r);
+                        xp[t][ct][r] = (owns(t) && i < D) ? p.forced[(size_t)i * NP + base + 16 * ct + c] : 0.0;
+                    }
+        } else {
             const double* uop = p.Uperm + lane;
 #pragma unroll
             for (int t = 0; t < TI; ++t) {

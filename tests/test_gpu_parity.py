@@ -285,6 +285,38 @@ def test_force_step(gpu):
     assert np.allclose(e.GetAcceptedLogLikelihood(), -0.5 * 5 * 0.25 ** 2)
 
 
+@pytest.mark.parametrize("exact", [True, False])
+def test_force_step_at_large_dim(gpu, oracle, exact):
+    """ForceStep for D > 63 (both large-dimension kernels): the forced point is proposed, tested and, with
+    Step(false, 2), taken; the proposal state does not move; the chain then continues like the reference chain
+    that was forced the same way."""
+    dim, n = 100, 70
+    e = gpu.Engine(dim, n, mode=gpu.MODE_FROZEN, exact=exact)
+    assert e.Start(np.zeros(dim))
+    e.Step(5)
+    trials = e.lane("trials").copy()
+    target = np.linspace(-0.2, 0.3, dim)
+    e.ForceStep(target)
+    e.Step(1, 2)
+    assert np.array_equal(e.GetAccepted(), np.repeat(target[:, None], n, axis=1))
+    assert np.array_equal(e.lane("trials"), trials)
+    e.ForceStep(np.full(dim, 10.0))            # far out: tested with the Metropolis rule, rejected everywhere
+    e.Step(1)
+    assert np.array_equal(e.GetAccepted(), np.repeat(target[:, None], n, axis=1))
+    e.Step(6)
+    if exact:
+        for ch in (0, 69):
+            c = oracle.Chain(dim, chain_id=ch)
+            c.set_covariance_frozen(1)
+            assert c.start(np.zeros(dim))
+            c.run_quiet(5)
+            c.force_step(target); c.step(False, 2)
+            c.force_step(np.full(dim, 10.0)); c.step(False, 0)
+            c.run_quiet(6)
+            assert np.array_equal(c.accepted, e.GetAccepted()[:, ch])
+            assert c.scalars["sigma"] == e.lane("sigma")[ch] and c.scalars["trials"] == e.lane("trials")[ch]
+
+
 def test_save_buffer(gpu):
     import torch
     dim, n, steps, stride = 5, 70, 20, 4

@@ -120,3 +120,46 @@ def test_hmc_example_runs(gpu, tmp_path, fused):
     logl = np.array([float(r_[col["LogLikelihood"]]) for r_ in rows])
     assert len(np.unique(x1)) > trials // 2 and np.all(np.isfinite(logl))   # the chain moves
     assert logl[-1] < logl[0]                                         # potential falls from U(p = 1) toward equilibrium
+
+
+def _walk(logl, r, randomize):
+    """TSimpleMCMC.H:305-333 restated: which entry Restore settles on, and the uniforms drawn."""
+    total, acc, used, elem = -1, 0.0, 0, len(logl)
+    while elem > 1:
+        elem -= 1
+        if total > 0:
+            new_p, old_p = np.exp(logl[elem]), np.exp(acc)
+            u = r[used]
+            used += 1
+            if new_p < (new_p + old_p) * u:
+                continue
+        total, acc = elem, logl[elem]
+        if not randomize:
+            break
+    return total, used
+
+
+@pytest.mark.parametrize("randomize", [0, 1])
+def test_restore_walk_matches_the_reference(smcmc, tmp_path, randomize):
+    exe = str(tmp_path / "walk.exe")
+    cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-Werror", f"-I{os.path.join(ROOT, 'include')}",
+           os.path.join(ROOT, "tests", "cpp", "restore_walk.C"), f"-L{LIBDIR}", "-lsmcmc_amd",
+           f"-Wl,-rpath,{LIBDIR}", "-Wl,-rpath,/opt/rocm/lib", "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    rng = np.random.default_rng(5)
+    for case in range(6):
+        n = 12 + case
+        logl = -rng.uniform(0.0, 3.0, n)
+        u = rng.uniform(size=n)
+        out = subprocess.run([exe, str(randomize), str(n)] + [repr(float(v)) for v in logl] +
+                             [repr(float(v)) for v in u], capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr
+        lines = out.stdout.split("\n")
+        total, used, x0, trials = lines[0].split()
+        want_total, want_used = _walk(logl, u, bool(randomize))
+        assert (int(total), int(used)) == (want_total, want_used)
+        assert float(x0) == want_total              # the point travels with the entry
+        assert int(trials) == 100 + n - 1           # the adaptive state always comes from the last entry (:1540-1570)
+        lo, hi = map(float, lines[1].split())
+        assert 0.0 < lo < 1e-3 and 1 - 1e-3 < hi < 1.0

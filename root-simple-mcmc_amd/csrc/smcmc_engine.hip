@@ -154,11 +154,24 @@ int upload_shared(smcmc_engine* h) {
         // Uperm[w][i][jl] = U(i, jl*W + w): every wavefront's columns contiguous per row
         const int D = h->dim, W = h->panel_w;
         std::vector<double> perm((size_t)W * D * kPanelCW, 0.0);
+        // dimensions with a uniform proposal take no part in the Gaussian step (TSimpleMCMC.H:711-716, 721)
+        std::vector<double> Uz(h->prop->decomp);
+        std::vector<double> bounds((size_t)2 * D + 8, 0.0);
+        uint64_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < D; ++i) {
+            if (h->prop->ptype[i] != 1) continue;
+            for (int j = 0; j < D; ++j) Uz[(size_t)i * D + j] = Uz[(size_t)j * D + i] = 0.0;
+            bounds[i] = h->prop->param1[i];
+            bounds[D + i] = h->prop->param2[i];
+            mask[i >> 6] |= (uint64_t)1 << (i & 63);
+        }
+        std::memcpy(&bounds[(size_t)2 * D], mask, sizeof(mask));
+        HIP_TRY(h, hipMemcpyAsync(h->d_uniform, bounds.data(), bounds.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
         for (int w = 0; w < W; ++w)
             for (int i = 0; i < D; ++i)
                 for (int jl = 0; jl < kPanelCW; ++jl) {
                     const int j = jl * W + w;
-                    if (j < D) perm[((size_t)w * D + i) * kPanelCW + jl] = h->prop->decomp[(size_t)i * D + j];
+                    if (j < D) perm[((size_t)w * D + i) * kPanelCW + jl] = Uz[(size_t)i * D + j];
                 }
         HIP_TRY(h, hipMemcpyAsync(h->d_U, perm.data(), perm.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
         if (!h->exact && !h->prop->decompFull) {
@@ -169,7 +182,7 @@ int upload_shared(smcmc_engine* h) {
                 for (int kq = 0; kq < nkq; ++kq)
                     for (int l = 0; l < 64; ++l) {
                         const int i = 4 * kq + (l >> 4), j = 16 * jt + (l & 15);
-                        if (i < D && j < D) uop[((size_t)jt * nkqp + kq) * 64 + l] = h->prop->decomp[(size_t)i * D + j];
+                        if (i < D && j < D) uop[((size_t)jt * nkqp + kq) * 64 + l] = Uz[(size_t)i * D + j];
                     }
             HIP_TRY(h, hipMemcpyAsync(h->d_Uop, uop.data(), uop.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
         }
@@ -278,7 +291,7 @@ StepParams make_params(smcmc_engine* h, int nsteps, int metropolis) {
     p.gacc = h->d_gacc;
     p.save_x = nullptr; p.save_logl = nullptr; p.save_stride = 1;
     p.uniform = h->d_uniform;
-    for (int d = 0; d < h->dim; ++d)
+    for (int d = 0; d < h->dim && d < 64; ++d)   // the register kernels (dim <= 63); larger dimensions carry theirs in d_uniform
         if (P.ptype[d] == 1) p.uniform_mask |= (uint64_t)1 << d;
     p.scan_dim = h->scan_dim;
     if (h->scan_dim >= 0) {
@@ -318,7 +331,15 @@ int launch(smcmc_engine* h, int nsteps, int metropolis, int stride, double* save
         q.x = p.x; q.lane_f64 = p.lane_f64; q.lane_i32 = p.lane_i32;
         q.save_stride = 1;
         q.has_forced = p.has_forced; q.forced = p.forced;
+        q.uniform = p.uniform; q.scan_dim = p.scan_dim; q.scan_uniform = p.scan_uniform;
+        q.scan_a = p.scan_a; q.scan_b = p.scan_b;
+        for (int d = 0; d < h->dim; ++d)
+            if (h->prop->ptype[d] == 1) q.special = 1;
+        if (p.scan_dim >= 0) q.special = 1;
         const bool exact = h->exact || h->prop->decompFull;
+        if (q.special && !exact)
+            return fail(h, SMCMC_ERR_UNSUPPORTED,
+                        "uniform proposals and the scan of a dimension run in reference-order arithmetic only");
         if (exact && h->likelihood == SMCMC_LIKE_QUADFORM)
             return fail(h, SMCMC_ERR_UNSUPPORTED, "the quadratic-form likelihood for dim > 63 runs in the fused order only");
         const bool pooled = (h->mode == SMCMC_MODE_POOLED);
@@ -331,7 +352,8 @@ int launch(smcmc_engine* h, int nsteps, int metropolis, int stride, double* save
             int seg = nsteps - done;
             if (pooled) {
                 const int phase = (int)(h->total_steps % (uint32_t)h->moment_stride);
-                if (phase == 0 && !q.has_forced) {   // a forced step does not call UpdateState: nothing to fold
+                // a forced step or a scan does not call UpdateState: nothing to fold
+                if (phase == 0 && !q.has_forced && q.scan_dim < 0) {
                     hipError_t e = launch_fold(h->d_x, h->d_c0, h->nchains, h->npad, h->dim, h->slice_chains, h->fold_nslices, h->d_gacc,
                                                h->stream);
                     if (e != hipSuccess) return fail(h, SMCMC_ERR_HIP, std::string("fold kernel launch: ") + hipGetErrorString(e));
@@ -456,8 +478,8 @@ int smcmc_create(int dim, int nchains, int likelihood, uint64_t seed, uint32_t c
     HIP_TRY(h, hipMalloc(&h->d_chunks, sizeof(double) * npacked(h) * ((h->ngroups + kReduceChunk - 1) / kReduceChunk)));
     HIP_TRY(h, hipMemset(h->d_x, 0, sizeof(double) * np * dp));
     HIP_TRY(h, hipMemset(h->d_forced, 0, sizeof(double) * np * dp));
-    HIP_TRY(h, hipMalloc(&h->d_uniform, sizeof(double) * 2 * dp));
-    HIP_TRY(h, hipMemset(h->d_uniform, 0, sizeof(double) * 2 * dp));
+    HIP_TRY(h, hipMalloc(&h->d_uniform, sizeof(double) * (2 * dp + 8)));
+    HIP_TRY(h, hipMemset(h->d_uniform, 0, sizeof(double) * (2 * dp + 8)));
     HIP_TRY(h, hipMemset(h->d_lane_f64, 0, sizeof(double) * np * SMCMC_LANE_F64_COUNT_));
     HIP_TRY(h, hipMemset(h->d_lane_i32, 0, sizeof(int32_t) * np * SMCMC_LANE_I32_COUNT_));
     HIP_TRY(h, hipMemset(h->d_like, 0, sizeof(double) * like_doubles));
@@ -513,7 +535,6 @@ int smcmc_set_gaussian(smcmc_engine* h, int dim, double sigma) {
 int smcmc_set_uniform(smcmc_engine* h, int dim, double minimum, double maximum) {
     if (!h) return SMCMC_ERR_INVALID;
     if (dim < 0 || dim >= h->dim) return fail(h, SMCMC_ERR_INVALID, "Dimension is out of range.");
-    if (h->panel_w) return fail(h, SMCMC_ERR_UNSUPPORTED, "uniform per-dimension proposals for dim > 63 are not on the HIP path yet");
     h->prop->ptype[dim] = 1;                                                                        // :845-847
     h->prop->param1[dim] = minimum;
     h->prop->param2[dim] = maximum;
@@ -522,8 +543,6 @@ int smcmc_set_uniform(smcmc_engine* h, int dim, double minimum, double maximum) 
 
 int smcmc_set_scan_dimension(smcmc_engine* h, int dim) {
     if (!h) return SMCMC_ERR_INVALID;
-    if (h->panel_w && dim >= 0 && dim < h->dim)
-        return fail(h, SMCMC_ERR_UNSUPPORTED, "scan of a dimension for dim > 63 is not on the HIP path yet");
     h->scan_dim = (dim < 0 || dim >= h->dim) ? -1 : dim;                                            // :827-829
     return SMCMC_OK;
 }

@@ -9,9 +9,9 @@
 
 namespace smcmc {
 
-template <int W, int CW, int LIKE, bool EXACT>
+template <int W, int CW, int LIKE, bool SPECIAL>
 static hipError_t go_panel(const PanelParams& p, hipStream_t s) {
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(panel_step_kernel<W, CW, LIKE, EXACT>), dim3(p.npad / kWave),
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(panel_step_kernel<W, CW, LIKE, true, SPECIAL>), dim3(p.npad / kWave),
                        dim3(W * kWave), 0, s, p);
     return hipGetLastError();
 }
@@ -19,13 +19,14 @@ static hipError_t go_panel(const PanelParams& p, hipStream_t s) {
 template <>
 hipError_t launch_panel<SMCMC_PANEL_W, kPanelCW>(const PanelParams& p, int like, bool exact, hipStream_t s) {
     constexpr int W = SMCMC_PANEL_W, CW = kPanelCW;
+    if (!exact) return hipErrorInvalidValue;   // the fused order is smcmc_panel_mfma_kernel.hip.h
     switch (like) {
         case SMCMC_LIKE_ISO_GAUSS:
-            return exact ? go_panel<W, CW, SMCMC_LIKE_ISO_GAUSS, true>(p, s)
-                         : go_panel<W, CW, SMCMC_LIKE_ISO_GAUSS, false>(p, s);
+            return p.special ? go_panel<W, CW, SMCMC_LIKE_ISO_GAUSS, true>(p, s)
+                             : go_panel<W, CW, SMCMC_LIKE_ISO_GAUSS, false>(p, s);
         case SMCMC_LIKE_ROSENBROCK:
-            return exact ? go_panel<W, CW, SMCMC_LIKE_ROSENBROCK, true>(p, s)
-                         : go_panel<W, CW, SMCMC_LIKE_ROSENBROCK, false>(p, s);
+            return p.special ? go_panel<W, CW, SMCMC_LIKE_ROSENBROCK, true>(p, s)
+                             : go_panel<W, CW, SMCMC_LIKE_ROSENBROCK, false>(p, s);
         default: return hipErrorInvalidValue;
     }
 }

@@ -430,7 +430,7 @@ def test_quadratic_form_at_large_dim_needs_the_fused_order(gpu, oracle):
 
 # ---------------------------------------------------------------- uniform dimensions and scan
 @pytest.mark.parametrize("mode", ["frozen", "pooled"])
-@pytest.mark.parametrize("kind,dim,nchains", [(0, 5, 70), (2, 6, 64), (0, 50, 128)])
+@pytest.mark.parametrize("kind,dim,nchains", [(0, 5, 70), (2, 6, 64), (0, 50, 128), (0, 70, 130), (2, 300, 64)])
 def test_uniform_dimensions_match_oracle(gpu, oracle, mode, kind, dim, nchains):
     """SetUniform (TSimpleMCMC.H:833-848, 711-716, 721): the uniform dimensions are redrawn
     from their range every step and take no part in the Gaussian move."""
@@ -459,20 +459,22 @@ def test_uniform_dimensions_match_oracle(gpu, oracle, mode, kind, dim, nchains):
     assert len(np.unique(x[1])) > x.shape[1] // 2
 
 
-def test_uniform_needs_reference_order(gpu):
-    e = gpu.Engine(5, 10, exact=False)
+@pytest.mark.parametrize("dim", [5, 100])
+def test_uniform_needs_reference_order(gpu, dim):
+    e = gpu.Engine(dim, 10, exact=False)
     e.SetUniform(2, -1.0, 1.0)
-    e.Start(np.zeros(5))
+    e.Start(np.zeros(dim))
     with pytest.raises(gpu.SmcmcError) as err:
         e.Step(1)
     assert err.value.status == 5   # SMCMC_ERR_UNSUPPORTED
 
 
+@pytest.mark.parametrize("dim,sd", [(6, 3), (90, 77)])
 @pytest.mark.parametrize("uniform", [False, True])
-def test_scan_dimension_matches_reference_chain(gpu, oracle, uniform):
+def test_scan_dimension_matches_reference_chain(gpu, oracle, uniform, dim, sd):
     """SetScanDimension (TSimpleMCMC.H:685-704, 820-830): only that dimension is redrawn (about
     the estimated centre, or uniformly) and the proposal state stays as it was."""
-    dim, nchains, sd, steps = 6, 70, 3, 40
+    nchains, steps = 70, 40
     e = gpu.Engine(dim, nchains, mode=gpu.MODE_FROZEN)
     if uniform:
         e.SetUniform(sd, -2.0, 1.0)

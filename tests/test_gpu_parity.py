@@ -360,7 +360,9 @@ def test_full_size_d50_properties(gpu):
 
 # ---------------------------------------------------------------- large dimensions (panel kernel)
 @pytest.mark.parametrize("kind,dim,nchains,steps", [(0, 64, 70, 40), (0, 200, 130, 25), (2, 200, 64, 30),
-                                                     (0, 257, 64, 12), (0, 500, 96, 10), (2, 500, 64, 10)])
+                                                     (0, 257, 64, 12), (0, 500, 96, 10), (2, 500, 64, 10),
+                                                     # the edges of the kernels' tilings: 128 | 129, 256 | 257, 512 = max
+                                                     (0, 128, 64, 8), (2, 129, 64, 8), (2, 256, 70, 8), (0, 512, 64, 6)])
 @pytest.mark.parametrize("exact", [True, False])
 def test_frozen_large_dim_matches_oracle(gpu, oracle, kind, dim, nchains, steps, exact):
     """BASELINE configs 3/4 shapes (D=200 Rosenbrock, D=500): a workgroup of 4 or 8
@@ -419,6 +421,13 @@ def test_quadratic_form_at_large_dim_in_the_fused_order(gpu, oracle, mode, dim, 
             e.sync(); o.sync()
             assert np.array_equal(e.decomposition, o.decomposition)
     assert e.lane("naccept").sum() > 0
+
+
+def test_dimension_limit_is_reported(gpu):
+    assert gpu.load().smcmc_max_dim() == 512
+    with pytest.raises(gpu.SmcmcError) as err:
+        gpu.Engine(513, 64)
+    assert err.value.status == 5   # SMCMC_ERR_UNSUPPORTED, no host fallback
 
 
 def test_quadratic_form_at_large_dim_needs_the_fused_order(gpu, oracle):

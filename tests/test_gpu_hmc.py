@@ -55,7 +55,8 @@ def test_hmc_rosenbrock_matches_reference_chain(gpu, oracle, dim, nchains, leap)
     _check(gpu, oracle, dim, nchains, 2, [100.0], x0, 0.004, leap, 8)
 
 
-@pytest.mark.parametrize("dim,nchains,leap", [(5, 70, 20), (100, 64, 20), (300, 64, 6)])
+@pytest.mark.parametrize("dim,nchains,leap", [(5, 70, 20), (100, 64, 20), (300, 64, 6), (63, 64, 4), (64, 40, 4),
+                                              (128, 64, 3), (129, 33, 3), (256, 64, 2), (257, 64, 2), (512, 32, 2)])
 def test_hmc_quadratic_form_matches_reference_chain(gpu, oracle, dim, nchains, leap):
     """The D x D gradient contraction of TDummyLogLikelihood.H:34-42 (config 5's hot loop)."""
     err = _spd(dim, dim)
@@ -63,7 +64,8 @@ def test_hmc_quadratic_form_matches_reference_chain(gpu, oracle, dim, nchains, l
 
 
 @pytest.mark.parametrize("dim,nchains,leap", [(5, 70, 20), (16, 33, 3), (100, 64, 20), (300, 96, 6), (500, 64, 4),
-                                              (512, 32, 2)])
+                                              (512, 32, 2), (63, 64, 4), (64, 40, 4), (128, 64, 3), (129, 33, 3),
+                                              (256, 64, 2), (257, 64, 2)])
 def test_hmc_quadratic_form_on_the_matrix_pipe(gpu, oracle, dim, nchains, leap):
     """Fused order: the gradient contraction as a chain of v_mfma_f64_16x16x4_f64 (32 chains per
     workgroup, positions / momenta / gradients in the matrix layout), bit for bit the oracle's

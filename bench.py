@@ -48,37 +48,22 @@ def cpu_baseline(seconds=12.0):
                       f"oracle/oracle_core.h compiled gcc -O2 (no -march), {dt:.1f} s"}
 
 
-ESS_STEPS, ESS_STRIDE, ESS_CHAINS = 8192, 16, 512
+ESS_STEPS, ESS_STRIDE = 8192, 16
 
 
 def measure_ess(eng, torch, dim):
-    """Effective samples per chain-step of the current (adapted) ensemble."""
+    """Effective samples per chain-step of the current (adapted) ensemble: the trace of every chain stays on the
+    device, smcmc_autocorrelation_sums pools the lagged products (MakeAutocorrelation.C:108-148), the host turns
+    64 lags x dim numbers into the integrated autocorrelation time (worst dimension)."""
     slots = ESS_STEPS // ESS_STRIDE
     npad, dpad = eng.nchains_padded, eng.dim_padded
     sx = torch.empty((slots, dpad, npad), dtype=torch.float64, device="cuda")
     sl = torch.empty((slots, npad), dtype=torch.float64, device="cuda")
     eng.StepSave(ESS_STEPS, sx.data_ptr(), sl.data_ptr(), stride=ESS_STRIDE)
     torch.cuda.synchronize()
-    nch = min(ESS_CHAINS, eng.nchains)
-    x = sx[:, :dim, :nch].cpu().numpy()                     # [slot][dim][chain]
+    tau = eng.AutocorrelationSums(sx.data_ptr(), slots, stream=torch.cuda.current_stream().cuda_stream).tau()
     del sx, sl
-    n = x.shape[0]
-    x = x - x.mean(axis=0, keepdims=True)
-    f = np.fft.rfft(x, n=2 * n, axis=0)
-    acov = np.fft.irfft(f * np.conj(f), axis=0)[:n].real    # [lag][dim][chain]
-    acov = acov.mean(axis=2)                                # pooled over chains
-    rho = acov / acov[0]
-    taus = []
-    for d in range(dim):
-        r = rho[:, d]
-        tau = 1.0
-        for k in range(1, n - 1, 2):                        # Geyer: sum pairs while positive
-            pair = r[k] + r[k + 1]
-            if pair < 0:
-                break
-            tau += 2.0 * pair
-        taus.append(tau)
-    return 1.0 / (max(taus) * ESS_STRIDE)
+    return 1.0 / (float(tau.max()) * ESS_STRIDE)
 
 
 def main():

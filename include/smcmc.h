@@ -255,6 +255,20 @@ int smcmc_selftest_mfma(int device, int K, const double* a, const double* b, dou
 /* The same for v_mfma_f64_4x4x4_4b_f64 as the moment fold uses it: c[4][16] = sum_k a[4][k] b[k][16]. */
 int smcmc_selftest_mfma_strip(int device, int K, const double* a, const double* b, double* c);
 
+/* ---- posterior reducer: autocorrelation of a saved trace ----------------------
+ * MakeAutocorrelation.C:108-148 defines a(lag) = (E[x_t x_(t-lag)] - mean^2) / var per dimension.
+ * This takes its sums on the device from a trace smcmc_step_save wrote
+ * (trace_device[slot][dim_stride][nchains_padded]), pooled over slots and chains, about the
+ * reference point `centre` ([dim] host; NULL = 0 is the macro's definition, another point changes a(lag)
+ * only through the edges of the lagged sums, O(lag / nslots), and conditions E[xx] - mean^2 better):
+ *   sum[d]       = sum_{t, c} y            y = x[t][d][c] - centre[d]
+ *   lagged[k][d] = sum_{t >= k, c} y_t y_(t-k)     k = 0 .. SMCMC_AUTOCORR_LAGS - 1
+ * (host outputs; the number of terms is (nslots - k) * nchains).  Raw sums so that ranks can add
+ * theirs.  Fixed summation order: the same bits on every run.  `stream` is a hipStream_t or NULL. */
+#define SMCMC_AUTOCORR_LAGS 64
+int smcmc_autocorrelation_sums(const double* trace_device, int nslots, int dim, int dim_stride, int nchains,
+                               int nchains_padded, const double* centre, double* sum, double* lagged, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

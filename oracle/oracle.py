@@ -449,3 +449,35 @@ def hmc_gradient(kind, p, params=None):
     p = _f64(p); prm = like_params(kind, p.size, params); g = np.zeros_like(p)
     lib().oracle_hmc_gradient(kind, p.size, _p(p), _p(prm) if prm.size else None, _p(g))
     return g
+
+
+# ---- autocorrelation of a saved trace (MakeAutocorrelation.C:108-148) ------------------------------
+def autocorrelation_sums(x, centre=None, nlags=64):
+    """x[slot][dim][chain].  The sums the macro's profile histograms hold (:112-122), pooled over chains and taken
+    about `centre`: sum[d] = sum y, lagged[k][d] = sum_{t>=k} y_t y_(t-k)."""
+    x = np.asarray(x, dtype=np.float64)
+    y = x - (0.0 if centre is None else np.asarray(centre, dtype=np.float64)[None, :, None])
+    n = y.shape[0]
+    lagged = np.zeros((nlags, y.shape[1]))
+    for k in range(min(nlags, n)):
+        lagged[k] = (y[k:] * y[:n - k]).sum(axis=(0, 2))
+    return y.sum(axis=(0, 2)), lagged
+
+
+def autocorrelation_reference(series, maxlag):
+    """MakeAutocorrelation.C:106-139 for one dimension of one chain, loop for loop: the ring buffer fill, then
+    a(lag) = (v / e - mean^2) / err^2 with mean and err the profile histogram's mean and spread (option "s")."""
+    series = np.asarray(series, dtype=np.float64)
+    prod, count = np.zeros(maxlag), np.zeros(maxlag)
+    for t, val in enumerate(series):
+        fills = t + 1
+        for lag in range(1, maxlag):
+            if fills <= lag:
+                break
+            prod[lag] += series[t - lag] * val
+            count[lag] += 1.0
+    mean = series.mean()
+    err2 = (series * series).mean() - mean * mean
+    a = np.full(maxlag, np.nan)
+    a[1:] = (prod[1:] / count[1:] - mean * mean) / err2
+    return a

@@ -101,7 +101,10 @@ SIGNATURES = {
     "smcmc_selftest_detmath": (C.c_int, [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp]),
     "smcmc_selftest_mfma": (C.c_int, [C.c_int, C.c_int, _dp, _dp, _dp]),
     "smcmc_selftest_mfma_strip": (C.c_int, [C.c_int, C.c_int, _dp, _dp, _dp]),
+    "smcmc_autocorrelation_sums": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp,
+                                             C.c_void_p]),
 }
+AUTOCORR_LAGS = 64
 
 _lib = None
 _libs = {}

@@ -45,7 +45,7 @@ def _units(user_flag=None):
     """(source, defines, object name).  With a user likelihood only the engine and the SMCMC_LIKE_USER
     instances are compiled with it; every other object is shared with the plain build."""
     engine = ("smcmc_engine.hip", [user_flag], "engine_user") if user_flag else ("smcmc_engine.hip", [], "engine")
-    units = [engine, ("smcmc_selftest.hip", [], "selftest"),
+    units = [engine, ("smcmc_selftest.hip", [], "selftest"), ("smcmc_autocorr.hip", [], "autocorr"),
              ("smcmc_hmc_engine.hip", [], "hmc_engine"), ("smcmc_hmc_mfma_inst.hip", [], "hmc_mfma"),
              ("smcmc_panel_mfma_inst.hip", [], "panel_mfma")]
     for dp in dp_list():

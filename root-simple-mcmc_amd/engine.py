@@ -200,6 +200,18 @@ class Engine:
         self._check(self._lib.smcmc_step_save(self._h, int(nsteps), int(metropolis), int(stride),
                                               C.c_void_p(int(save_x_ptr)), C.c_void_p(int(save_logl_ptr))))
 
+    def AutocorrelationSums(self, trace_ptr, nslots, centre=None, stream=0):
+        """Lagged-product sums of a trace StepSave wrote ([slot][dim_padded][nchains_padded] on the device), pooled
+        over slots and chains about `centre` (default: the origin, as the macro has it): the inputs of the reference's
+        autocorrelation (MakeAutocorrelation.C:108-148).  Returns an Autocorrelation."""
+        c = _f64(np.zeros(self.dim) if centre is None else centre)
+        s = np.zeros(self.dim)
+        lagged = np.zeros((_capi.AUTOCORR_LAGS, self.dim))
+        self._check(self._lib.smcmc_autocorrelation_sums(C.c_void_p(int(trace_ptr)), int(nslots), self.dim,
+                                                         self.dim_padded, self.nchains, self.nchains_padded, _ptr(c),
+                                                         _ptr(s), _ptr(lagged), C.c_void_p(int(stream))))
+        return Autocorrelation(s, lagged, int(nslots), self.nchains)
+
     def GetAccepted(self):
         x = np.zeros((self.dim, self.nchains))
         self._check(self._lib.smcmc_read_state(self._h, _ptr(x), None))
@@ -265,6 +277,40 @@ class Engine:
         x, l = C.c_void_p(), C.c_void_p()
         self._check(self._lib.smcmc_state_device_ptr(self._h, C.byref(x), C.byref(l)))
         return x.value, l.value
+
+
+class Autocorrelation:
+    """a(lag) = (E[x_t x_(t-lag)] - mean^2) / var per dimension (MakeAutocorrelation.C:127-139) from the pooled sums
+    of Engine.AutocorrelationSums; sums of several ranks add (`+`)."""
+
+    def __init__(self, total, lagged, nslots, nchains):
+        self.sum, self.lagged, self.nslots, self.nchains = np.array(total), np.array(lagged), nslots, nchains
+
+    def __add__(self, other):
+        if self.nslots != other.nslots:
+            raise ValueError("traces of different lengths do not pool")
+        return Autocorrelation(self.sum + other.sum, self.lagged + other.lagged, self.nslots, self.nchains + other.nchains)
+
+    def rho(self):
+        """[lag][dim]"""
+        nlag = min(self.lagged.shape[0], self.nslots)
+        n = (self.nslots - np.arange(nlag))[:, None] * float(self.nchains)
+        mean = self.sum / n[0]
+        var = self.lagged[0] / n[0] - mean * mean
+        return (self.lagged[:nlag] / n - mean * mean) / var
+
+    def tau(self):
+        """Integrated autocorrelation time per dimension in slots: 1 + 2 sum rho, the sum cut where a pair of
+        consecutive lags turns negative (initial positive sequence)."""
+        rho = self.rho()
+        out = np.ones(rho.shape[1])
+        for d in range(rho.shape[1]):
+            for k in range(1, rho.shape[0] - 1, 2):
+                pair = rho[k, d] + rho[k + 1, d]
+                if pair < 0:
+                    break
+                out[d] += 2.0 * pair
+        return out
 
 
 class PosteriorMoments:

@@ -49,8 +49,10 @@ out["config4_iso_d500_32768_frozen_fused_matrix_pipe"] = {
     "chain_steps_per_s": 32768 * 32 / dt, "ms_per_step": dt / 32 * 1e3,
     "proposal_TFLOPs": 32768 * 32 / dt * 500 * 501 / 1e12}
 # config 4 with the header-form TDummyLogLikelihood (quadratic form, Error from Init()): fused order only at D > 63
-from oracle import oracle as O  # noqa: E402  (only for TDummyLogLikelihood::Init's Error matrix)
-err = O.dummy_error_matrix(500)[1]
+# TDummyLogLikelihood::Init() (TDummyLogLikelihood.H:44-142): identity covariance except the (0, D-1) pair
+cov = np.eye(500)
+cov[0, 499] = cov[499, 0] = 0.999999
+err = np.linalg.inv(cov)
 e = pkg.Engine(500, 32768, likelihood=pkg.LIKE_QUADFORM, likelihood_params=err, mode=pkg.MODE_FROZEN, exact=False)
 e.Start(np.zeros(500))
 dt = timed(lambda: e.Step(32), 3)

@@ -35,8 +35,8 @@ __global__ void __launch_bounds__(kWave) autocorr_partial_kernel(const double* _
                                                                  const double* __restrict__ centre,
                                                                  double* __restrict__ partial) {
     const int lane = threadIdx.x;
-    const int d = blockIdx.x;
-    const int cb = blockIdx.y;
+    const int cb = blockIdx.x;   // neighbouring workgroups read neighbouring 512-byte pieces of a trace row
+    const int d = blockIdx.y;
     const size_t chain = (size_t)cb * kWave + lane;
     const bool active = chain < (size_t)nchains;
     const double c0 = centre[d];
@@ -116,10 +116,10 @@ extern "C" int smcmc_autocorrelation_sums(const double* trace_device, int nslots
         if (centre) {
             if (hipMemcpyAsync(d_centre, centre, sizeof(double) * dim, hipMemcpyHostToDevice, s) != hipSuccess) break;
         } else if (hipMemsetAsync(d_centre, 0, sizeof(double) * dim, s) != hipSuccess) break;
-        hipLaunchKernelGGL(autocorr_partial_kernel<0>, dim3(dim, nblocks), dim3(kWave), 0, s, trace_device, nslots, dim,
+        hipLaunchKernelGGL(autocorr_partial_kernel<0>, dim3(nblocks, dim), dim3(kWave), 0, s, trace_device, nslots, dim,
                            (size_t)dim_stride, nchains, (size_t)nchains_padded, d_centre, d_partial);
         if (hipGetLastError() != hipSuccess) break;
-        hipLaunchKernelGGL(autocorr_partial_kernel<kPassLags>, dim3(dim, nblocks), dim3(kWave), 0, s, trace_device, nslots,
+        hipLaunchKernelGGL(autocorr_partial_kernel<kPassLags>, dim3(nblocks, dim), dim3(kWave), 0, s, trace_device, nslots,
                            dim, (size_t)dim_stride, nchains, (size_t)nchains_padded, d_centre, d_partial);
         if (hipGetLastError() != hipSuccess) break;
         hipLaunchKernelGGL(autocorr_reduce_kernel, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, s, d_partial, nblocks,

@@ -61,6 +61,12 @@ struct PanelParams {
     double scan_a, scan_b;    // uniform: bounds; Gaussian: centre, sigma
 };
 
+template <int W>
+__device__ __forceinline__ size_t step_pitch(size_t np) {
+    if constexpr (W == 4) asm volatile("" : "+s"(np));
+    return np;
+}
+
 // SPECIAL = the instantiation that also knows uniform per-dimension proposals and the scan of one dimension
 // (kept out of the common kernel: with them in, D=500 went from 0.89 to 2.85 ms/step)
 template <int W, int CW, int LIKE, bool EXACT, bool SPECIAL>
@@ -115,6 +121,10 @@ __global__ void __launch_bounds__(W * kWave) panel_step_kernel(const PanelParams
     double xp[CW];
     for (int s = 0; s < p.nsteps; ++s) {
         const uint64_t step = (uint64_t)(p.step0 + (uint32_t)s + 1u);
+        // W = 4: the row pitch is opaque per step, otherwise the 3 x 64 column addresses are hoisted out of the
+        // step loop and live in (spilled) registers for the whole launch (D=200: 0.145 -> 0.129 ms/step).  At
+        // W = 8 recomputing them costs more than the spills (D=500: 0.877 -> 0.912 ms/step): left hoisted.
+        const size_t NPl = step_pitch<W>(NP);
 
         // ForceStep (TSimpleMCMC.H:671-678): the proposal is the forced point, the proposal state is not updated
         const bool forced_now = p.has_forced && s == 0;
@@ -162,7 +172,7 @@ __global__ void __launch_bounds__(W * kWave) panel_step_kernel(const PanelParams
 #pragma unroll
         for (int jl = 0; jl < CW; ++jl) {
             const int j = jl * W + w;
-            xp[jl] = (j < D) ? xsrc[(size_t)j * NP + chain] : 0.0;
+            xp[jl] = (j < D) ? xsrc[(size_t)j * (W == 4 ? NPl : NP) + chain] : 0.0;
         }
         uint32_t uword = 0;
         if (no_update && w == 0) {
@@ -280,7 +290,7 @@ __global__ void __launch_bounds__(W * kWave) panel_step_kernel(const PanelParams
                 const int jl = g * kGatherJl + q;
                 if (jl < CW) {
                     const int j = jl * W + w;
-                    const double xv = (j < D) ? p.x[(size_t)j * NP + chain] : 0.0;
+                    const double xv = (j < D) ? p.x[(size_t)j * (W == 4 ? NPl : NP) + chain] : 0.0;
                     ulds[(q * W + w) * kWave + lane] = xp[jl];
                     ulds[kGd + (q * W + w) * kWave + lane] = xp[jl] - xv;
                 }
@@ -366,7 +376,7 @@ __global__ void __launch_bounds__(W * kWave) panel_step_kernel(const PanelParams
 #pragma unroll
             for (int jl = 0; jl < CW; ++jl) {
                 const int j = jl * W + w;
-                if (j < D) p.x[(size_t)j * NP + chain] = xp[jl];
+                if (j < D) p.x[(size_t)j * (W == 4 ? NPl : NP) + chain] = xp[jl];
             }
         }
         if (p.save_x != nullptr && ((s + 1) % p.save_stride) == 0 && active) {
@@ -374,9 +384,9 @@ __global__ void __launch_bounds__(W * kWave) panel_step_kernel(const PanelParams
 #pragma unroll
             for (int jl = 0; jl < CW; ++jl) {
                 const int j = jl * W + w;
-                if (j < D) p.save_x[(slot * (size_t)D + (size_t)j) * NP + chain] = take ? xp[jl] : p.x[(size_t)j * NP + chain];
+                if (j < D) p.save_x[(slot * (size_t)D + (size_t)j) * (W == 4 ? NPl : NP) + chain] = take ? xp[jl] : p.x[(size_t)j * (W == 4 ? NPl : NP) + chain];
             }
-            if (w == 0) p.save_logl[slot * NP + chain] = logl;
+            if (w == 0) p.save_logl[slot * (W == 4 ? NPl : NP) + chain] = logl;
         }
         __syncthreads();                           // x is final before the next step reads x[0] / its columns
     }

@@ -62,9 +62,7 @@ typedef struct {
     int moment_stride;         /* fold the point seen at the start of step t when (t-1) % stride == 0 */
     double* acc;               /* [group][packed (D+1)(D+2)/2] */
     double* c0;                /* centre the moments are taken about */
-    /* pending per-lane adjustments from the last pooled update */
-    double pending_sigma_scale;
-    int pending_deweight;
+    double last_sigma_scale;   /* sigma rescale factor of the latest pooled update (diagnostic) */
 } oracle_ensemble;
 
 static int ens_npacked(int dim) { return (dim + 1) * (dim + 2) / 2; }
@@ -105,8 +103,7 @@ oracle_ensemble* oracle_ensemble_create(int nchains, int dim, int like_kind, con
     e->ngroups = (nchains + 63) / 64;
     e->acc = (double*)calloc((size_t)e->ngroups * (size_t)ens_npacked(dim), sizeof(double));
     e->c0 = (double*)calloc(d, sizeof(double));
-    e->pending_sigma_scale = 1.0;
-    e->pending_deweight = 0;
+    e->last_sigma_scale = 1.0;
     return e;
 }
 
@@ -238,16 +235,6 @@ static void ens_step_once(oracle_ensemble* e, int metropolis) {
     const double max_up = (double)D * (double)D;
     for (int c = 0; c < N; ++c) {
         for (int d = 0; d < D; ++d) x[d] = e->x[(size_t)d * (size_t)N + (size_t)c];
-        /* pending adjustments from the last pooled update: sigma rescale
-         * (TSimpleMCMC.H:1042) and acceptance de-weighting (:1081-1086) */
-        if (e->pending_sigma_scale != 1.0 || e->pending_deweight) {
-            e->sigma[c] = e->sigma[c] * e->pending_sigma_scale;
-            if (e->pending_deweight && P->acceptance_deweight > 0.0) {
-                double w = 1.0 - fmin(P->acceptance_deweight, 1.0);
-                e->acceptance_trials[c] = fmax(1.0, w * e->acceptance_trials[c]);
-                e->acceptance_trials[c] = fmin(e->acceptance_trials[c], w * P->acceptance_window);
-            }
-        }
         /* --- UpdateState, scalar half (TSimpleMCMC.H:1723-1776) --- */
         int moved = (e->logl[c] != e->last_value[c] || x[0] != e->last_x0[c]);
         int accepted = oracle_update_scalars(&e->trials[c], &e->successes[c], &e->acceptance[c],
@@ -342,8 +329,6 @@ static void ens_step_once(oracle_ensemble* e, int metropolis) {
             e->naccept[c]++;
         }
     }
-    e->pending_sigma_scale = 1.0;
-    e->pending_deweight = 0;
     free(x); free(xp); free(y);
 }
 
@@ -369,6 +354,9 @@ void oracle_ensemble_reduce_moments(oracle_ensemble* e, double* moments) {
     }
     memset(e->acc, 0, sizeof(double) * (size_t)e->ngroups * (size_t)npk);
 }
+
+static void ens_adjust_lanes(oracle_ensemble* e, double scale);
+static void ens_after_update(oracle_ensemble* e);
 
 /* Pooled update from (all-reduced) moments about c0: the reference running
  * averages (TSimpleMCMC.H:1780-1820) fed with a batch of n points, followed by
@@ -404,17 +392,84 @@ void oracle_ensemble_apply_moments(oracle_ensemble* e, const double* M) {
         P->cov_trials = fmin(P->cov_window, P->cov_trials + n);
     }
     free(delta);
-    double old_trace = P->sigma_trace;
-    double sigma_before = P->sigma;
-    P->sigma = 1.0;                               /* capture the rescale factor */
     int succ = 0;
     for (int c = 0; c < e->nchains; ++c) succ += e->successes[c];
     P->successes = succ;
     oracle_proposal_update(P, 0);
-    e->pending_sigma_scale = P->sigma;            /* = sqrt(old_trace / new_trace) */
-    P->sigma = sigma_before * e->pending_sigma_scale;
-    e->pending_deweight = 1;
-    (void)old_trace;
+    e->last_sigma_scale = P->last_sigma_scale;    /* = sqrt(old_trace / new_trace) */
+    ens_after_update(e);
+}
+
+/* smcmc_set_covariance: overwrite fCurrentCov of the shared proposal (takes effect at the next update) */
+void oracle_ensemble_set_covariance(oracle_ensemble* e, const double* cov) {
+    memcpy(e->prop.cov, cov, sizeof(double) * (size_t)e->dim * (size_t)e->dim);
+}
+
+/* what an UpdateProposal on the shared proposal does to every chain's scalars: sigma rescale
+ * (TSimpleMCMC.H:1042-1043) and acceptance de-weighting (:1081-1086) */
+static void ens_adjust_lanes(oracle_ensemble* e, double scale) {
+    const oracle_proposal* P = &e->prop;
+    for (int c = 0; c < e->nchains; ++c) {
+        e->sigma[c] = e->sigma[c] * scale;
+        if (P->acceptance_deweight > 0.0) {
+            double w = 1.0 - fmin(P->acceptance_deweight, 1.0);
+            e->acceptance_trials[c] = fmax(1.0, w * e->acceptance_trials[c]);
+            e->acceptance_trials[c] = fmin(e->acceptance_trials[c], w * P->acceptance_window);
+        }
+    }
+}
+
+static void ens_reset_lanes(oracle_ensemble* e) {
+    const oracle_proposal* P = &e->prop;
+    const int D = e->dim;
+    for (int c = 0; c < e->nchains; ++c) {
+        e->trials[c] = 0; e->successes[c] = 0;
+        e->next_update[c] = P->next_update;
+        e->acceptance[c] = P->acceptance;
+        e->acceptance_trials[c] = P->acceptance_trials;
+        if (e->sigma[c] < 0.01 * sqrt(1.0 / D)) e->sigma[c] = sqrt(1.0 / D);
+    }
+    memset(e->acc, 0, sizeof(double) * (size_t)e->ngroups * (size_t)ens_npacked(D));
+}
+
+/* The consequences of an UpdateProposal on the shared proposal for the chains (the engine's update_shared):
+ * sigma rescale and de-weighting per chain; when the ladder ended in ResetProposal (TSimpleMCMC.H:1389) the
+ * chains are reset with it, the shared centre restarting from chain 0's current point. */
+static void ens_after_update(oracle_ensemble* e) {
+    oracle_proposal* P = &e->prop;
+    const int N = e->nchains, D = e->dim;
+    ens_adjust_lanes(e, e->last_sigma_scale);
+    if (P->last_update_path == 4) {
+        for (int d = 0; d < D; ++d) P->last_point[d] = P->central[d] = e->x[(size_t)d * (size_t)N];
+        ens_reset_lanes(e);
+    }
+    memcpy(e->c0, P->central, sizeof(double) * (size_t)D);
+}
+
+/* smcmc_update_proposal: the user's UpdateProposal() (TSimpleMCMC.H:1009) on the shared proposal.  FROZEN: every
+ * chain reschedules its own next update from its own successes (:1050-1052). */
+void oracle_ensemble_update_proposal(oracle_ensemble* e) {
+    oracle_proposal* P = &e->prop;
+    oracle_proposal_update(P, 0);
+    e->last_sigma_scale = P->last_sigma_scale;
+    if (P->failed) return;
+    ens_after_update(e);
+    if (e->mode == ENS_MODE_FROZEN && P->last_update_path != 4) {
+        const double max_up = (double)e->dim * (double)e->dim;
+        for (int c = 0; c < e->nchains; ++c)
+            e->next_update[c] = (int)(P->acceptance_window + max_up - max_up / (0.5 * e->successes[c] + 1.0));
+    }
+}
+
+/* smcmc_reset_proposal: ResetProposal() (TSimpleMCMC.H:1396-1494) on the shared proposal, whose fLastPoint is
+ * chain 0's current point; every chain's counters, acceptance history and (floored) sigma follow :1405-1410, 1481-1482. */
+void oracle_ensemble_reset_proposal(oracle_ensemble* e) {
+    oracle_proposal* P = &e->prop;
+    const int N = e->nchains, D = e->dim;
+    for (int d = 0; d < D; ++d) P->last_point[d] = e->x[(size_t)d * (size_t)N];
+    oracle_proposal_reset(P);
+    if (P->failed) return;
+    ens_reset_lanes(e);
     memcpy(e->c0, P->central, sizeof(double) * (size_t)D);
 }
 
@@ -458,10 +513,10 @@ void oracle_ensemble_get_center(const oracle_ensemble* e, double* out) { memcpy(
 void oracle_ensemble_get_covariance(const oracle_ensemble* e, double* out) { memcpy(out, e->prop.cov, sizeof(double) * (size_t)e->dim * (size_t)e->dim); }
 void oracle_ensemble_get_decomposition(const oracle_ensemble* e, double* out) { memcpy(out, e->prop.decomp, sizeof(double) * (size_t)e->dim * (size_t)e->dim); }
 /* 0 sigma_trace 1 cov_trials 2 central_trials 3 cov_window 4 acceptance_window 5 target
- * 6 total_steps 7 update_count 8 last_update_path 9 failed 10 pending_sigma_scale 11 decomp_full */
+ * 6 total_steps 7 update_count 8 last_update_path 9 failed 10 last_sigma_scale 11 decomp_full */
 void oracle_ensemble_get_shared(const oracle_ensemble* e, double* out) {
     const oracle_proposal* p = &e->prop;
     out[0] = p->sigma_trace; out[1] = p->cov_trials; out[2] = p->central_trials; out[3] = p->cov_window;
     out[4] = p->acceptance_window; out[5] = p->target; out[6] = e->total_steps; out[7] = p->update_count;
-    out[8] = p->last_update_path; out[9] = p->failed; out[10] = e->pending_sigma_scale; out[11] = p->decomp_full;
+    out[8] = p->last_update_path; out[9] = p->failed; out[10] = e->last_sigma_scale; out[11] = p->decomp_full;
 }

@@ -108,7 +108,8 @@ def _declare(L):
         ("set_acceptance_deweight", [C.c_double]), ("set_acceptance_rigidity", [C.c_double]),
         ("set_target_acceptance", [C.c_double]), ("set_step_rms_window", [C.c_int]),
         ("set_sigma", [C.c_double]), ("set_moment_grouping", [C.c_int, C.c_int]), ("set_quadform_rowwise", [C.c_int]),
-        ("step", [C.c_int, C.c_int]), ("reduce_moments", [_dp]),
+        ("step", [C.c_int, C.c_int]), ("reduce_moments", [_dp]), ("set_covariance", [_dp]),
+        ("update_proposal", []), ("reset_proposal", []),
         ("apply_moments", [_dp]), ("sync", []), ("get_x", [_dp]), ("get_lane_f64", [C.c_int, _dp]),
         ("get_lane_i32", [C.c_int, _ip]), ("get_last_accept", [_bp]), ("get_center", [_dp]),
         ("get_covariance", [_dp]), ("get_decomposition", [_dp]), ("get_shared", [_dp]),
@@ -262,7 +263,7 @@ LANE_F64 = {"logl": 0, "sigma": 1, "acceptance": 2, "acceptance_trials": 3, "rig
 LANE_I32 = {"trials": 0, "successes": 1, "next_update": 2, "naccept": 3, "step_rms_trials": 4}
 SHARED_NAMES = ["sigma_trace", "cov_trials", "central_trials", "cov_window", "acceptance_window",
                 "target", "total_steps", "update_count", "last_update_path", "failed",
-                "pending_sigma_scale", "decomp_full"]
+                "last_sigma_scale", "decomp_full"]
 
 
 class Ensemble:
@@ -280,8 +281,13 @@ class Ensemble:
             lib().oracle_ensemble_destroy(self._h)
             self._h = None
 
+    def set_covariance(self, cov):
+        cov = _f64(cov)
+        assert cov.shape == (self.dim, self.dim)
+        lib().oracle_ensemble_set_covariance(self._h, _p(cov))
+
     def __getattr__(self, name):
-        if name.startswith("set_") or name == "sync":
+        if name.startswith("set_") or name in ("sync", "update_proposal", "reset_proposal"):
             f = getattr(lib(), "oracle_ensemble_" + name)
             return lambda *a: f(self._h, *a)
         raise AttributeError(name)

@@ -145,6 +145,7 @@ typedef struct {
     int update_count;         /* diagnostics: number of UpdateProposal calls */
     int last_update_path;     /* 0 chol, 1 conditioned chol, 2 eigen, 3 emergency, 4 reset */
     int failed;               /* set instead of throwing */
+    double last_sigma_scale;  /* sqrt(old trace / new trace) of the latest UpdateProposal (ensemble bookkeeping) */
 } oracle_proposal;
 
 /* constructor TSimpleMCMC.H:642-655 */
@@ -309,7 +310,8 @@ static void oracle_proposal_update(oracle_proposal* p, int from_reset) {
     double current_trace = oracle_proposal_trace(p);                /* :1024 */
     if (current_trace <= 0) { p->failed = 1; return; }              /* :1025-1028 throws */
 
-    p->sigma = p->sigma * sqrt(p->sigma_trace / current_trace);     /* :1042 */
+    const double sigma_scale = sqrt(p->sigma_trace / current_trace);
+    p->sigma = p->sigma * sigma_scale;                              /* :1042 */
     p->sigma_trace = current_trace;                                 /* :1043 */
 
     double max_up = (double)n * (double)n;                          /* :1050 (size_t product) */
@@ -331,6 +333,7 @@ static void oracle_proposal_update(oracle_proposal* p, int from_reset) {
         p->acceptance_trials = fmin(p->acceptance_trials, w * p->acceptance_window);
     }
     p->last_update_path = oracle_decompose_ladder(p, from_reset);
+    p->last_sigma_scale = sigma_scale;   /* after the ladder: a reset on its last rung runs this function again */
 }
 
 /* ResetProposal TSimpleMCMC.H:1396-1494 */

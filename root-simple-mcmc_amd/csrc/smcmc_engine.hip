@@ -79,9 +79,6 @@ struct smcmc_engine {
     hipStream_t stream = nullptr;
     SharedProposal* prop = nullptr;
     std::vector<double> like_params;
-    // pending per-chain adjustments from the last pooled UpdateProposal
-    double pending_sigma_scale = 1.0;
-    int pending_deweight = 0;
     bool has_forced = false;
     // device
     double* d_x = nullptr;
@@ -124,6 +121,55 @@ int status_of(smcmc_engine* h, UpdateStatus st) {
         case UpdateStatus::TargetNotSet: return fail(h, SMCMC_ERR_RUNTIME, "Target acceptance not initialized");
     }
     return SMCMC_ERR_RUNTIME;
+}
+
+// Every entry point that touches the device runs on the engine's own device and leaves the
+// caller's current device as it found it (two engines on two devices may share a thread).
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(int device) {
+        if (hipGetDevice(&prev) == hipSuccess && prev != device) switched = (hipSetDevice(device) == hipSuccess);
+    }
+    ~DeviceGuard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+#define ON_DEVICE(h) DeviceGuard device_guard_((h)->device)
+
+// What UpdateProposal does to the per-chain scalars (TSimpleMCMC.H:1042-1043, 1081-1086): sigma is rescaled
+// by sqrt(old trace / new trace) and the acceptance trials are de-weighted.  Applied to every chain's
+// column at the update itself, so that what is read or saved afterwards is what the reference would hold.
+__global__ void adjust_lanes_kernel(double* lane_f64, int npad, int nchains, double sigma_scale, double acc_w,
+                                    double acc_wW) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nchains) return;
+    double* sg = lane_f64 + (size_t)SMCMC_LANE_SIGMA * npad + c;
+    *sg = *sg * sigma_scale;
+    if (acc_w >= 0.0) {
+        double* at = lane_f64 + (size_t)SMCMC_LANE_ACCEPTANCE_TRIALS * npad + c;
+        double t = *at;
+        t = dmax(1.0, acc_w * t);
+        t = dmin(t, acc_wW);
+        *at = t;
+    }
+}
+
+// ResetProposal's effect on every chain's scalars (TSimpleMCMC.H:1405-1410, 1481-1482): counters cleared, the
+// acceptance history erased, a collapsed sigma put back to sqrt(1/D); next_update as UpdateProposal(true) leaves it.
+__global__ void reset_lanes_kernel(double* lane_f64, int32_t* lane_i32, int npad, int nchains, int next_update,
+                                   double acceptance, double acceptance_trials, double sigma_floor, double sigma_reset) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nchains) return;
+    lane_i32[(size_t)SMCMC_LANE_TRIALS * npad + c] = 0;
+    lane_i32[(size_t)SMCMC_LANE_SUCCESSES * npad + c] = 0;
+    lane_i32[(size_t)SMCMC_LANE_NEXT_UPDATE * npad + c] = next_update;
+    lane_f64[(size_t)SMCMC_LANE_ACCEPTANCE * npad + c] = acceptance;
+    lane_f64[(size_t)SMCMC_LANE_ACCEPTANCE_TRIALS * npad + c] = acceptance_trials;
+    double* sg = lane_f64 + (size_t)SMCMC_LANE_SIGMA * npad + c;
+    if (*sg < sigma_floor) *sg = sigma_reset;
 }
 
 size_t npacked(const smcmc_engine* h) { return (size_t)(h->dim + 1) * (h->dim + 2) / 2; }
@@ -257,6 +303,67 @@ int upload_like(smcmc_engine* h) {
     return SMCMC_OK;
 }
 
+// sigma rescale + acceptance de-weighting of every chain after an UpdateProposal on the shared proposal
+int adjust_lanes(smcmc_engine* h, double sigma_scale) {
+    const SharedProposal& P = *h->prop;
+    double acc_w = -1.0, acc_wW = 0.0;
+    if (P.acceptanceDeweight > 0.0) {
+        acc_w = 1.0 - std::min(P.acceptanceDeweight, 1.0);
+        acc_wW = acc_w * P.acceptanceWindow;
+    }
+    const int threads = 256;
+    hipLaunchKernelGGL(adjust_lanes_kernel, dim3((h->nchains + threads - 1) / threads), dim3(threads), 0, h->stream,
+                       h->d_lane_f64, h->npad, h->nchains, sigma_scale, acc_w, acc_wW);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(h, SMCMC_ERR_HIP, std::string("adjust_lanes launch: ") + hipGetErrorString(e));
+    return SMCMC_OK;
+}
+
+// chain 0's current point: fLastPoint of the shared proposal when it is reset (TSimpleMCMC.H:1484-1485)
+int read_chain0(smcmc_engine* h, std::vector<double>& x0) {
+    x0.assign(h->dim, 0.0);
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipMemcpy2D(x0.data(), sizeof(double), h->d_x, (size_t)h->npad * sizeof(double), sizeof(double),
+                           (size_t)h->dim, hipMemcpyDeviceToHost));
+    return SMCMC_OK;
+}
+
+int reset_lanes(smcmc_engine* h) {
+    const SharedProposal& P = *h->prop;
+    const int threads = 256;
+    const double sr = std::sqrt(1.0 / h->dim);
+    hipLaunchKernelGGL(reset_lanes_kernel, dim3((h->nchains + threads - 1) / threads), dim3(threads), 0, h->stream,
+                       h->d_lane_f64, h->d_lane_i32, h->npad, h->nchains, P.nextUpdate, P.acceptance,
+                       P.acceptanceTrials, 0.01 * sr, sr);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(h, SMCMC_ERR_HIP, std::string("reset_lanes launch: ") + hipGetErrorString(e));
+    return SMCMC_OK;
+}
+
+
+// UpdateProposal() on the shared proposal and its consequences for the chains: every chain's sigma is
+// rescaled by the factor the shared template was, sqrt(old trace / new trace) (TSimpleMCMC.H:1042), and its
+// acceptance trials are de-weighted (:1081-1086); when the decomposition ladder ended in ResetProposal (:1389)
+// the chains are reset with it, about chain 0's current point.
+int update_shared(smcmc_engine* h) {
+    SharedProposal& P = *h->prop;
+    int st = status_of(h, P.update(false));
+    if (st) return st;
+    st = adjust_lanes(h, P.lastSigmaScale);
+    if (st) return st;
+    if (P.lastPath == 4) {
+        std::vector<double> x0;
+        st = read_chain0(h, x0);
+        if (st) return st;
+        P.lastPoint = x0;
+        P.centre = x0;
+        st = reset_lanes(h);
+        if (st) return st;
+        HIP_TRY(h, hipMemsetAsync(h->d_gacc, 0, sizeof(double) * gacc_doubles(h), h->stream));
+    }
+    return SMCMC_OK;
+}
+
 StepParams make_params(smcmc_engine* h, int nsteps, int metropolis) {
     const SharedProposal& P = *h->prop;
     StepParams p;
@@ -281,8 +388,6 @@ StepParams make_params(smcmc_engine* h, int nsteps, int metropolis) {
         p.acc_w = -1.0;
         p.acc_wW = 0.0;
     }
-    p.pending_sigma_scale = h->pending_sigma_scale;
-    p.pending_deweight = h->pending_deweight;
     p.per_lane_update = (h->mode == SMCMC_MODE_FROZEN) ? 1 : 0;
     p.step_rms_window = h->step_rms_window;
     p.has_forced = h->has_forced ? 1 : 0;
@@ -310,6 +415,7 @@ StepParams make_params(smcmc_engine* h, int nsteps, int metropolis) {
 
 int launch(smcmc_engine* h, int nsteps, int metropolis, int stride, double* save_x, double* save_logl) {
     if (!h) return SMCMC_ERR_INVALID;
+    ON_DEVICE(h);
     if (!h->started) return fail(h, SMCMC_ERR_INVALID, "Uninitialized starting point");   // TSimpleMCMC.H:371-374
     if (nsteps <= 0) return SMCMC_OK;
     if (metropolis < 0 || metropolis > 2) return fail(h, SMCMC_ERR_INVALID, "metropolis must be 0, 1 or 2");
@@ -325,8 +431,7 @@ int launch(smcmc_engine* h, int nsteps, int metropolis, int stride, double* save
         q.chain_offset = p.chain_offset; q.seed = p.seed;
         q.Uperm = h->d_U; q.like = h->d_like;
         q.target = p.target; q.acc_window = p.acc_window; q.asig = p.asig; q.max_up = p.max_up;
-        q.acc_w = p.acc_w; q.acc_wW = p.acc_wW; q.pending_sigma_scale = p.pending_sigma_scale;
-        q.pending_deweight = p.pending_deweight; q.per_lane_update = p.per_lane_update;
+        q.acc_w = p.acc_w; q.acc_wW = p.acc_wW; q.per_lane_update = p.per_lane_update;
         q.step_rms_window = p.step_rms_window; q.full_u = h->prop->decompFull ? 1 : 0;
         q.x = p.x; q.lane_f64 = p.lane_f64; q.lane_i32 = p.lane_i32;
         q.save_stride = 1;
@@ -375,12 +480,8 @@ int launch(smcmc_engine* h, int nsteps, int metropolis, int stride, double* save
             if (e != hipSuccess) return fail(h, SMCMC_ERR_HIP, std::string("panel kernel launch: ") + hipGetErrorString(e));
             h->total_steps += (uint32_t)seg;
             done += seg;
-            q.pending_sigma_scale = 1.0;
-            q.pending_deweight = 0;
             q.has_forced = 0;
         }
-        h->pending_sigma_scale = 1.0;
-        h->pending_deweight = 0;
         h->has_forced = false;
         return SMCMC_OK;
     }
@@ -393,8 +494,6 @@ int launch(smcmc_engine* h, int nsteps, int metropolis, int stride, double* save
     hipError_t e = dispatch_step(h->dp, p, h->likelihood, exact, fullu, moments, h->stream);
     if (e != hipSuccess) return fail(h, SMCMC_ERR_HIP, std::string("step kernel launch: ") + hipGetErrorString(e));
     h->total_steps += (uint32_t)nsteps;
-    h->pending_sigma_scale = 1.0;
-    h->pending_deweight = 0;
     h->has_forced = false;
     return SMCMC_OK;
 }
@@ -457,7 +556,7 @@ int smcmc_create(int dim, int nchains, int likelihood, uint64_t seed, uint32_t c
     h->slice_chains = ((h->ngroups + h->fold_nslices - 1) / h->fold_nslices) * kWave;
     h->prop = new SharedProposal(dim);
     *out = h;
-    HIP_TRY(h, hipSetDevice(device));
+    ON_DEVICE(h);
     const size_t np = (size_t)h->npad;
     const size_t u_doubles = panel_w ? (size_t)panel_w * dim * kPanelCW : (size_t)dp * dp;
     HIP_TRY(h, hipMalloc(&h->d_x, sizeof(double) * np * dp));        // rows >= dim stay zero
@@ -491,10 +590,8 @@ int smcmc_create(int dim, int nchains, int likelihood, uint64_t seed, uint32_t c
 
 int smcmc_destroy(smcmc_engine* h) {
     if (!h) return SMCMC_OK;
-    if (h->d_x) {
-        (void)hipSetDevice(h->device);
-        (void)hipStreamSynchronize(h->stream);
-    }
+    ON_DEVICE(h);
+    if (h->d_x) (void)hipStreamSynchronize(h->stream);
     (void)hipFree(h->d_x); (void)hipFree(h->d_forced); (void)hipFree(h->d_uniform); (void)hipFree(h->d_lane_f64); (void)hipFree(h->d_lane_i32);
     (void)hipFree(h->d_U); (void)hipFree(h->d_Uop); (void)hipFree(h->d_like); (void)hipFree(h->d_c0); (void)hipFree(h->d_gacc);
     (void)hipFree(h->d_moments); (void)hipFree(h->d_chunks);
@@ -511,6 +608,7 @@ int smcmc_set_stream(smcmc_engine* h, void* hip_stream) {
 
 int smcmc_set_likelihood_params(smcmc_engine* h, const double* params, int count) {
     if (!h || count < 0 || (count > 0 && !params)) return SMCMC_ERR_INVALID;
+    ON_DEVICE(h);
     h->like_params.assign(params, params + count);
     if (h->started) return upload_like(h);
     return SMCMC_OK;
@@ -525,6 +623,7 @@ int smcmc_set_mode(smcmc_engine* h, int mode) {
 
 int smcmc_set_gaussian(smcmc_engine* h, int dim, double sigma) {
     if (!h) return SMCMC_ERR_INVALID;
+    ON_DEVICE(h);
     if (dim < 0 || dim >= h->dim) return fail(h, SMCMC_ERR_INVALID, "Dimension is out of range.");   // :856-860
     const bool was_uniform = h->prop->ptype[dim] == 1;
     h->prop->ptype[dim] = 0;
@@ -534,6 +633,7 @@ int smcmc_set_gaussian(smcmc_engine* h, int dim, double sigma) {
 
 int smcmc_set_uniform(smcmc_engine* h, int dim, double minimum, double maximum) {
     if (!h) return SMCMC_ERR_INVALID;
+    ON_DEVICE(h);
     if (dim < 0 || dim >= h->dim) return fail(h, SMCMC_ERR_INVALID, "Dimension is out of range.");
     h->prop->ptype[dim] = 1;                                                                        // :845-847
     h->prop->param1[dim] = minimum;
@@ -584,6 +684,7 @@ static int broadcast_lane_i32(smcmc_engine* h, int field, int32_t v) {
 
 int smcmc_set_param(smcmc_engine* h, int which, double v) {
     if (!h) return SMCMC_ERR_INVALID;
+    ON_DEVICE(h);
     SharedProposal& P = *h->prop;
     switch (which) {
         case SMCMC_P_COVARIANCE_WINDOW: P.covWindow = v; return SMCMC_OK;
@@ -624,6 +725,7 @@ int smcmc_set_param(smcmc_engine* h, int which, double v) {
 
 int smcmc_get_param(smcmc_engine* h, int which, double* out) {
     if (!h || !out) return SMCMC_ERR_INVALID;
+    ON_DEVICE(h);
     const SharedProposal& P = *h->prop;
     switch (which) {
         case SMCMC_P_COVARIANCE_WINDOW: *out = P.covWindow; break;
@@ -662,7 +764,6 @@ int smcmc_get_param(smcmc_engine* h, int which, double* out) {
 // columns are zero afterwards except the likelihood; x and logl come back for the caller.
 static int place_chains(smcmc_engine* h, const double* x0, int broadcast, std::vector<double>& x,
                         std::vector<double>& logl) {
-    HIP_TRY(h, hipSetDevice(h->device));
     const int D = h->dim, N = h->nchains;
     const size_t NP = (size_t)h->npad;
     int st = upload_like(h);
@@ -684,7 +785,7 @@ static int place_chains(smcmc_engine* h, const double* x0, int broadcast, std::v
         std::memset(&q, 0, sizeof(q));
         q.nchains = N; q.npad = h->npad; q.dim = D; q.init_only = 1;
         q.like = h->d_like; q.x = h->d_x; q.lane_f64 = h->d_lane_f64; q.lane_i32 = h->d_lane_i32;
-        q.pending_sigma_scale = 1.0; q.save_stride = 1;
+        q.save_stride = 1;
         hipError_t e = launch_panel_mfma(q, h->likelihood, h->stream);
         if (e != hipSuccess) return fail(h, SMCMC_ERR_HIP, std::string("start kernel launch: ") + hipGetErrorString(e));
     } else if (h->panel_w) {
@@ -698,7 +799,6 @@ static int place_chains(smcmc_engine* h, const double* x0, int broadcast, std::v
         p.seed = h->seed; p.chain_offset = h->chain_offset;
         p.U = h->d_U; p.like = h->d_like; p.c0 = h->d_c0;
         p.target = 0.234; p.acc_window = 1.0; p.asig = 1.0; p.max_up = 1.0; p.acc_w = -1.0;
-        p.pending_sigma_scale = 1.0;
         p.step_rms_window = 0;
         p.has_forced = 1; p.forced = h->d_forced;
         p.x = h->d_x; p.lane_f64 = h->d_lane_f64; p.lane_i32 = h->d_lane_i32; p.gacc = h->d_gacc;
@@ -716,6 +816,7 @@ static int place_chains(smcmc_engine* h, const double* x0, int broadcast, std::v
 
 int smcmc_start(smcmc_engine* h, const double* x0, int broadcast) {
     if (!h || !x0) return SMCMC_ERR_INVALID;
+    ON_DEVICE(h);
     const int D = h->dim, N = h->nchains;
     const size_t NP = (size_t)h->npad;
     std::vector<double> x, logl;
@@ -753,8 +854,6 @@ int smcmc_start(smcmc_engine* h, const double* x0, int broadcast) {
     st = upload_shared(h);
     if (st) return st;
     h->total_steps = 0;
-    h->pending_sigma_scale = 1.0;
-    h->pending_deweight = 0;
     h->has_forced = false;
     h->started = true;
     return SMCMC_OK;
@@ -766,6 +865,7 @@ int smcmc_start(smcmc_engine* h, const double* x0, int broadcast) {
 // and is updated once (:1612).
 int smcmc_restore(smcmc_engine* h, const double* accepted, int broadcast, const smcmc_saved_state* s) {
     if (!h || !accepted || !s || !s->central_point || !s->covariance) return SMCMC_ERR_INVALID;
+    ON_DEVICE(h);
     if (!h->started)
         return fail(h, SMCMC_ERR_INVALID, "Restore needs a started chain (Start first, SimpleMCMC.C:151-154)");
     const int D = h->dim, N = h->nchains;
@@ -816,8 +916,6 @@ int smcmc_restore(smcmc_engine* h, const double* accepted, int broadcast, const 
     HIP_TRY(h, hipMemsetAsync(h->d_gacc, 0, sizeof(double) * gacc_doubles(h), h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->total_steps = (uint32_t)s->total_steps;
-    h->pending_sigma_scale = 1.0;
-    h->pending_deweight = 0;
     h->has_forced = false;
     return upload_shared(h);
 }
@@ -833,6 +931,7 @@ int smcmc_step_save(smcmc_engine* h, int nsteps, int metropolis, int stride, dou
 
 int smcmc_force_step(smcmc_engine* h, const double* point, int broadcast) {
     if (!h || !point) return SMCMC_ERR_INVALID;
+    ON_DEVICE(h);
     const int D = h->dim, N = h->nchains;
     const size_t NP = (size_t)h->npad;
     std::vector<double> x(NP * h->dp, 0.0);
@@ -848,6 +947,7 @@ int smcmc_moments_size(const smcmc_engine* h) { return h ? (int)npacked(h) : 0; 
 
 int smcmc_reduce_moments(smcmc_engine* h) {
     if (!h || !h->started) return SMCMC_ERR_INVALID;
+    ON_DEVICE(h);
     if (h->panel_w) {
         hipError_t e = launch_fold_reduce(h->d_gacc, h->dim, h->fold_nslices, h->d_moments, h->stream);
         if (e != hipSuccess) return fail(h, SMCMC_ERR_HIP, std::string("fold reduce launch: ") + hipGetErrorString(e));
@@ -862,18 +962,21 @@ int smcmc_reduce_moments(smcmc_engine* h) {
 
 int smcmc_export_moments(smcmc_engine* h, double* dst) {
     if (!h || !dst) return SMCMC_ERR_INVALID;
+    ON_DEVICE(h);
     HIP_TRY(h, hipMemcpyAsync(dst, h->d_moments, npacked(h) * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     return SMCMC_OK;
 }
 
 int smcmc_import_moments(smcmc_engine* h, const double* src) {
     if (!h || !src) return SMCMC_ERR_INVALID;
+    ON_DEVICE(h);
     HIP_TRY(h, hipMemcpyAsync(h->d_moments, src, npacked(h) * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     return SMCMC_OK;
 }
 
 int smcmc_read_moments(smcmc_engine* h, double* out) {
     if (!h || !out) return SMCMC_ERR_INVALID;
+    ON_DEVICE(h);
     HIP_TRY(h, hipMemcpyAsync(out, h->d_moments, npacked(h) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return SMCMC_OK;
@@ -881,22 +984,15 @@ int smcmc_read_moments(smcmc_engine* h, double* out) {
 
 int smcmc_apply_moments(smcmc_engine* h) {
     if (!h || !h->started) return SMCMC_ERR_INVALID;
+    ON_DEVICE(h);
     std::vector<double> M(npacked(h));
     int st = smcmc_read_moments(h, M.data());
     if (st) return st;
     SharedProposal& P = *h->prop;
     if (!(M[npacked(h) - 1] > 0.0)) return SMCMC_OK;
     P.absorbMoments(M.data(), h->mode == SMCMC_MODE_POOLED);
-    // UpdateProposal on the shared proposal; sigma = 1 going in captures the
-    // rescale factor sqrt(old trace / new trace) the chains apply (TSimpleMCMC.H:1042)
-    const double sigmaBefore = P.sigma;
-    P.sigma = 1.0;
-    st = status_of(h, P.update(false));
-    const double scale = P.sigma;
-    P.sigma = sigmaBefore * scale;
+    st = update_shared(h);
     if (st) return st;
-    h->pending_sigma_scale = scale;
-    h->pending_deweight = 1;
     return upload_shared(h);
 }
 
@@ -908,16 +1004,11 @@ int smcmc_sync(smcmc_engine* h) {
 
 int smcmc_update_proposal(smcmc_engine* h) {
     if (!h || !h->started) return SMCMC_ERR_INVALID;
+    ON_DEVICE(h);
     SharedProposal& P = *h->prop;
-    const double sigmaBefore = P.sigma;
-    P.sigma = 1.0;
-    int st = status_of(h, P.update(false));
-    const double scale = P.sigma;
-    P.sigma = sigmaBefore * scale;
+    int st = update_shared(h);
     if (st) return st;
-    h->pending_sigma_scale *= scale;
-    h->pending_deweight = 1;
-    if (h->mode == SMCMC_MODE_FROZEN) {
+    if (h->mode == SMCMC_MODE_FROZEN && P.lastPath != 4) {
         // every chain reschedules its own next update from its own successes (:1050-1052)
         const size_t NP = (size_t)h->npad;
         std::vector<int32_t> succ(NP), next(NP);
@@ -935,23 +1026,18 @@ int smcmc_update_proposal(smcmc_engine* h) {
 
 int smcmc_reset_proposal(smcmc_engine* h) {
     if (!h || !h->started) return SMCMC_ERR_INVALID;
+    ON_DEVICE(h);
     SharedProposal& P = *h->prop;
     // fLastPoint of the shared proposal := chain 0's current point
-    std::vector<double> x0(h->dim);
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    for (int d = 0; d < h->dim; ++d)
-        HIP_TRY(h, hipMemcpy(&x0[d], h->d_x + (size_t)d * h->npad, sizeof(double), hipMemcpyDeviceToHost));
-    P.lastPoint = x0;
-    int st = status_of(h, P.reset());
+    std::vector<double> x0;
+    int st = read_chain0(h, x0);
     if (st) return st;
-    st = broadcast_lane_i32(h, SMCMC_LANE_TRIALS, 0); if (st) return st;
-    st = broadcast_lane_i32(h, SMCMC_LANE_SUCCESSES, 0); if (st) return st;
-    st = broadcast_lane_i32(h, SMCMC_LANE_NEXT_UPDATE, P.nextUpdate); if (st) return st;
-    st = broadcast_lane_f64(h, SMCMC_LANE_ACCEPTANCE, P.acceptance); if (st) return st;
-    st = broadcast_lane_f64(h, SMCMC_LANE_ACCEPTANCE_TRIALS, P.acceptanceTrials); if (st) return st;
+    P.lastPoint = x0;
+    st = status_of(h, P.reset());
+    if (st) return st;
+    st = reset_lanes(h);
+    if (st) return st;
     HIP_TRY(h, hipMemsetAsync(h->d_gacc, 0, sizeof(double) * gacc_doubles(h), h->stream));
-    h->pending_sigma_scale = 1.0;
-    h->pending_deweight = 0;
     return upload_shared(h);
 }
 
@@ -960,6 +1046,7 @@ int smcmc_dim_padded(const smcmc_engine* h) { return h ? h->dp : 0; }
 
 int smcmc_read_state(smcmc_engine* h, double* x, double* logl) {
     if (!h) return SMCMC_ERR_INVALID;
+    ON_DEVICE(h);
     const int D = h->dim, N = h->nchains;
     const size_t NP = (size_t)h->npad;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -974,6 +1061,7 @@ int smcmc_read_state(smcmc_engine* h, double* x, double* logl) {
 
 int smcmc_read_lane_f64(smcmc_engine* h, int field, double* out) {
     if (!h || !out || field < 0 || field >= SMCMC_LANE_F64_COUNT_) return SMCMC_ERR_INVALID;
+    ON_DEVICE(h);
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     HIP_TRY(h, hipMemcpy(out, h->d_lane_f64 + (size_t)field * h->npad, (size_t)h->nchains * sizeof(double),
                          hipMemcpyDeviceToHost));
@@ -982,6 +1070,7 @@ int smcmc_read_lane_f64(smcmc_engine* h, int field, double* out) {
 
 int smcmc_read_lane_i32(smcmc_engine* h, int field, int32_t* out) {
     if (!h || !out || field < 0 || field >= SMCMC_LANE_I32_COUNT_) return SMCMC_ERR_INVALID;
+    ON_DEVICE(h);
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     HIP_TRY(h, hipMemcpy(out, h->d_lane_i32 + (size_t)field * h->npad, (size_t)h->nchains * sizeof(int32_t),
                          hipMemcpyDeviceToHost));
@@ -996,6 +1085,7 @@ int smcmc_get_center(smcmc_engine* h, double* out) {
 
 int smcmc_set_center(smcmc_engine* h, const double* in) {
     if (!h || !in) return SMCMC_ERR_INVALID;
+    ON_DEVICE(h);
     std::copy(in, in + h->dim, h->prop->centre.begin());
     return h->started ? upload_shared(h) : SMCMC_OK;
 }

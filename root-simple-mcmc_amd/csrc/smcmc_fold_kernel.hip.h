@@ -108,15 +108,23 @@ static __global__ void __launch_bounds__(kFoldWaves* kWave) fold_moments_kernel(
         }
     };
     // one stage: registers -> LDS, refill the registers two stages ahead, fold the 16 chains
+    // Every wavefront stages through its own LDS region (st_all[wv]) and the slices of a workgroup can differ in
+    // length, so the hand-over is ordered within the wavefront only: LDS operations of one wavefront complete in
+    // issue order, the fences keep the compiler from moving them across.
+    auto wave_lds_sync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
     auto consume = [&](int c, stage_t& stage) {
-        __syncthreads();   // the previous stage has been consumed
+        wave_lds_sync();   // the previous stage has been consumed
 #pragma unroll
         for (int op = 0; op < 2 * kFoldBT; ++op) {
             if (op >= nops) continue;
             *(f64x2*)&st[op][srow][4 * sq] = stage[op][0];
             *(f64x2*)&st[op][srow][4 * sq + 2] = stage[op][1];
         }
-        __syncthreads();
+        wave_lds_sync();
         if (c + 32 < c_end) fetch(c + 32, stage);   // in flight under the matrix instructions
 #pragma unroll
         for (int n = 0; n < 4; ++n) {

@@ -163,8 +163,6 @@ struct StepParams {
     const double* c0;          // [DP] centre the moments are taken about
     double target, acc_window, asig, max_up;
     double acc_w, acc_wW;      // acceptance de-weighting: w = 1 - deweight, w*window; acc_w < 0 = off
-    double pending_sigma_scale;
-    int pending_deweight;
     int per_lane_update;       // FROZEN mode: per-chain UpdateProposal schedule
     int step_rms_window;
     int has_forced;            // ForceStep pending: the first step proposes `forced`
@@ -324,14 +322,6 @@ __global__ void __launch_bounds__(kWave, 2) step_kernel(const StepParams p) {
     int naccept = li[SMCMC_LANE_NACCEPT * NP];
     int rms_trials = li[SMCMC_LANE_STEP_RMS_TRIALS * NP];
     int last_accept = li[SMCMC_LANE_LAST_ACCEPT * NP];
-
-    // adjustments left by the last pooled UpdateProposal: sigma rescale
-    // (TSimpleMCMC.H:1042) and acceptance de-weighting (:1081-1086)
-    sigma = sigma * p.pending_sigma_scale;
-    if (p.pending_deweight && p.acc_w >= 0.0) {
-        acc_trials = dmax(1.0, p.acc_w * acc_trials);
-        acc_trials = dmin(acc_trials, p.acc_wW);
-    }
 
     // stage U: lane-strided copy of each kept row segment
 #pragma unroll

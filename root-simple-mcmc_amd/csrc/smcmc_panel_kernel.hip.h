@@ -42,8 +42,8 @@ struct PanelParams {
     uint64_t seed;
     const double* Uperm;      // [W][dim][CW]
     const double* like;       // ROSENBROCK: {b}
-    double target, acc_window, asig, max_up, acc_w, acc_wW, pending_sigma_scale;
-    int pending_deweight, per_lane_update, step_rms_window, full_u;
+    double target, acc_window, asig, max_up, acc_w, acc_wW;
+    int per_lane_update, step_rms_window, full_u;
     double* x;                // [dim][npad]
     double* lane_f64;
     int32_t* lane_i32;
@@ -108,11 +108,6 @@ __global__ void __launch_bounds__(W * kWave) panel_step_kernel(const PanelParams
     int rms_trials = li[SMCMC_LANE_STEP_RMS_TRIALS * NP];
     int last_accept = li[SMCMC_LANE_LAST_ACCEPT * NP];
 
-    sigma = sigma * p.pending_sigma_scale;
-    if (p.pending_deweight && p.acc_w >= 0.0) {
-        acc_trials = dmax(1.0, p.acc_w * acc_trials);
-        acc_trials = dmin(acc_trials, p.acc_wW);
-    }
 
     const uint32_t aw = smcmc_accept_word((uint32_t)D);
     const int npanels = (D + kPanelRows - 1) / kPanelRows;

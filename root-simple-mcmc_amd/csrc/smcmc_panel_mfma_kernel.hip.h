@@ -142,11 +142,6 @@ __global__ void __launch_bounds__(kPmW* kWave, 1) panel_mfma_kernel(const PanelP
         naccept = li[SMCMC_LANE_NACCEPT * NP];
         rms_trials = li[SMCMC_LANE_STEP_RMS_TRIALS * NP];
         last_accept = li[SMCMC_LANE_LAST_ACCEPT * NP];
-        sigma = sigma * p.pending_sigma_scale;
-        if (p.pending_deweight && p.acc_w >= 0.0) {
-            acc_trials = dmax(1.0, p.acc_w * acc_trials);
-            acc_trials = dmin(acc_trials, p.acc_wW);
-        }
         x0s[lane] = p.x[mychain];
     }
 

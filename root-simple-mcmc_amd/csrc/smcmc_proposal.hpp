@@ -45,6 +45,7 @@ public:
     double maxCorrelation;
     bool initialized = false, decompFull = false;
     int updateCount = 0, lastPath = 0;
+    double lastSigmaScale = 1.0;   // sqrt(old trace / new trace) of the latest update(): what every chain's sigma takes
 
     double& C(int i, int j) { return cov[(size_t)i * D + j]; }
     double& U(int i, int j) { return decomp[(size_t)i * D + j]; }
@@ -109,7 +110,8 @@ public:
         ++updateCount;
         const double currentTrace = trace();
         if (currentTrace <= 0) return UpdateStatus::InvalidTrace;
-        sigma = sigma * std::sqrt(sigmaTrace / currentTrace);
+        const double sigmaScale = std::sqrt(sigmaTrace / currentTrace);
+        sigma = sigma * sigmaScale;
         sigmaTrace = currentTrace;
         const double maxUp = (double)D * (double)D;
         const double up = 0.5 * successes;
@@ -128,7 +130,9 @@ public:
             acceptanceTrials = std::max(1.0, w * acceptanceTrials);
             acceptanceTrials = std::min(acceptanceTrials, w * acceptanceWindow);
         }
-        return decompose(fromReset);
+        const UpdateStatus st = decompose(fromReset);
+        lastSigmaScale = sigmaScale;   // after the ladder: a reset on its last rung runs update() again
+        return st;
     }
 
     // Batch form of the running averages :1780-1820.  M is the packed moment

@@ -113,7 +113,9 @@ class Engine:
     def SetTargetAcceptance(self, a): self.set_param("TARGET_ACCEPTANCE", a)
     def GetTargetAcceptance(self): return self.get_param("TARGET_ACCEPTANCE")
     def SetSigma(self, s): self.set_param("SIGMA", s)
-    def GetSigma(self): return self.get_param("SIGMA")
+    def GetSigma(self, chain=None):
+        """fSigma (TSimpleMCMC.H:770): of chain 0 by default, of `chain` otherwise."""
+        return self.get_param("SIGMA") if chain is None else float(self.lane("sigma")[chain])
     def SetMaximumCorrelation(self, c): self.set_param("MAXIMUM_CORRELATION", c)
     def SetStepRMSWindow(self, n): self.set_param("STEP_RMS_WINDOW", n)
     def SetNextUpdate(self, n): self.set_param("NEXT_UPDATE", n)
@@ -266,6 +268,14 @@ class Engine:
         out = np.zeros((self.dim, self.dim))
         self._check(self._lib.smcmc_get_covariance(self._h, _ptr(out)))
         return out
+
+    def SetCovariance(self, cov):
+        """Overwrite fCurrentCov ([dim][dim]); takes effect at the next UpdateProposal (the hook the reference's
+        IMPOSE_RANDOM_CORRELATIONS experiment uses through SetCorrelation, SimpleMCMC.C:107-115)."""
+        cov = _f64(cov)
+        if cov.shape != (self.dim, self.dim):
+            raise ValueError("covariance must be [dim][dim]")
+        self._check(self._lib.smcmc_set_covariance(self._h, _ptr(cov)))
 
     @property
     def decomposition(self):

@@ -1,0 +1,282 @@
+"""The BASELINE configurations on their real workloads, and the rarely taken product paths, through the C ABI
+against the CPU oracle (bit for bit, as tests/test_gpu_parity.py).
+
+* config 3: pooled THardLogLikelihood (Rosenbrock) at D = 200;
+* config 4: pooled D = 500, README-form and header-form TDummyLogLikelihood, and its exchange step with the
+  ensemble cut into two engines (the RCCL all-reduce replaced by a device-side add, so it runs on one GPU);
+* TProposeAdaptiveStep::UpdateProposal's decomposition ladder (TSimpleMCMC.H:1134-1389): conditioned Cholesky,
+  eigen-decomposition (the FULLU kernels), emergency shrink, reset -- each forced through smcmc_set_covariance /
+  smcmc_set_correlation and followed by steps;
+* ResetProposal (TSimpleMCMC.H:1396-1494) in the middle of a run.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(gpu, oracle, dim, nchains, kind, mode, exact, offset=0, rowwise=False, stride=1):
+    prm = oracle.like_params(kind, dim)
+    prm = prm if prm.size else None
+    e = gpu.Engine(dim, nchains, likelihood=kind, likelihood_params=prm, chain_offset=offset, mode=mode, exact=exact)
+    o = oracle.Ensemble(nchains, dim, kind=kind, params=prm, chain_offset=offset, mode=mode, exact=exact)
+    if rowwise:
+        o.set_quadform_rowwise(1)
+    if dim > 63 and mode == gpu.MODE_POOLED:
+        e.set_param("MOMENT_STRIDE", stride)
+        o.set_moment_grouping(int(e.get_param("MOMENT_GROUP")), stride)
+    return e, o
+
+
+def _same(e, o, tag):
+    assert np.array_equal(e.GetAccepted(), o.x), f"{tag}: accepted points differ"
+    for name in ("logl", "sigma", "acceptance", "acceptance_trials", "rigidity", "step_rms", "logl_proposed"):
+        a, b = e.lane(name), o.lane(name)
+        assert np.array_equal(a, b), f"{tag}: lane field {name} differs (max |d| = {np.max(np.abs(a - b))})"
+    for name in ("trials", "successes", "next_update", "naccept", "step_rms_trials"):
+        assert np.array_equal(e.lane(name), o.lane(name)), f"{tag}: lane field {name} differs"
+
+
+def _same_shared(e, o, tag):
+    assert np.array_equal(e.covariance, o.covariance), f"{tag}: covariance"
+    assert np.array_equal(e.GetEstimatedCenter(), o.center), f"{tag}: centre"
+    assert np.array_equal(e.decomposition, o.decomposition), f"{tag}: decomposition"
+    assert e.get_param("LAST_UPDATE_PATH") == o.shared["last_update_path"], f"{tag}: ladder rung"
+    assert e.get_param("COVARIANCE_TRIALS") == o.shared["cov_trials"]
+    assert e.get_param("SIGMA_TRACE") == o.shared["sigma_trace"]
+
+
+# ---------------------------------------------------------------- BASELINE configs 3 and 4, pooled
+@pytest.mark.parametrize("exact", [True, False])
+@pytest.mark.parametrize("stride", [1, 16])
+def test_config4_pooled_d500_iso(gpu, oracle, exact, stride):
+    """Config 4's per-GPU workload in small: D = 500, pooled covariance, windows ending in a sync."""
+    dim, n, window = 500, 192, (4 if stride == 1 else 17)
+    e, o = _pair(gpu, oracle, dim, n, 0, gpu.MODE_POOLED, exact, stride=stride)
+    assert e.Start(np.zeros(dim)) and o.start(np.zeros(dim))
+    for w in range(2):
+        e.Step(window); o.step(window)
+        _same(e, o, f"window {w}")
+        e.reduce_moments()
+        m_gpu, m_cpu = e.read_moments(), o.reduce_moments()
+        assert np.array_equal(m_gpu, m_cpu), f"window {w}: moments"
+        assert m_gpu[-1] == n * len(range(0, window, stride)) if w == 0 else m_gpu[-1] > 0
+        e.apply_moments(); o.apply_moments(m_cpu)
+        _same_shared(e, o, f"window {w}")
+        _same(e, o, f"window {w} after the update")
+    e.Step(2); o.step(2)
+    _same(e, o, "after the last sync")
+
+
+def test_config4_pooled_d500_header_form(gpu, oracle):
+    """The likelihood config 4 names, TDummyLogLikelihood's header form (quadratic form, Error from Init()), pooled
+    at D = 500 on the matrix pipe (fused order, the oracle's row-wise association)."""
+    dim, n = 500, 128
+    e, o = _pair(gpu, oracle, dim, n, 1, gpu.MODE_POOLED, False, rowwise=True, stride=2)
+    x0 = np.full(dim, 0.02)
+    assert e.Start(x0) and o.start(x0)
+    for w in range(2):
+        e.Step(5); o.step(5)
+        _same(e, o, f"window {w}")
+        e.sync(); o.sync()
+        _same_shared(e, o, f"window {w}")
+    e.Step(2); o.step(2)
+    _same(e, o, "after the last sync")
+
+
+@pytest.mark.parametrize("exact", [True, False])
+def test_config3_pooled_rosenbrock_d200(gpu, oracle, exact):
+    dim, n = 200, 256
+    rng = np.random.default_rng(200)
+    e, o = _pair(gpu, oracle, dim, n, 2, gpu.MODE_POOLED, exact, stride=4)
+    x0 = rng.uniform(0.5, 1.5, size=(dim, n))                       # SimpleMCMC.C:147
+    assert e.Start(x0) and o.start(x0)
+    for w in range(3):
+        e.Step(8); o.step(8)
+        _same(e, o, f"window {w}")
+        e.sync(); o.sync()
+        _same_shared(e, o, f"window {w}")
+    e.Step(3); o.step(3)
+    _same(e, o, "after the last sync")
+    assert e.lane("naccept").sum() > 0
+
+
+# ---------------------------------------------------------------- the config-4 exchange on one GPU
+def _exchange(torch, engines):
+    """What ranks do between windows (distributed.run_windows): reduce, export, sum, import, apply."""
+    bufs = []
+    for e in engines:
+        e.reduce_moments()
+        b = torch.zeros(e.moments_size, dtype=torch.float64, device="cuda")
+        e.export_moments(b.data_ptr())
+        bufs.append(b)
+    total = bufs[0].clone()
+    for b in bufs[1:]:
+        total += b
+    for e in engines:
+        e.import_moments(total.data_ptr())
+        e.apply_moments()
+    torch.cuda.synchronize()
+    return total.cpu().numpy()
+
+
+def test_sharded_exchange_d50_equals_one_engine(gpu, oracle):
+    """Two engines of 2048 chains (one reduction chunk each) with chain offsets, moments exported, added on the
+    device and imported = one engine of 4096 chains, bit for bit: the exchange of config 4 minus RCCL."""
+    import torch
+    dim, n, window = 50, 4096, 8
+    whole = gpu.Engine(dim, n)
+    halves = [gpu.Engine(dim, n // 2, chain_offset=k * (n // 2)) for k in range(2)]
+    ref = oracle.Ensemble(n, dim)
+    for e in [whole] + halves:
+        assert e.Start(np.zeros(dim))
+    assert ref.start(np.zeros(dim))
+    for w in range(3):
+        whole.Step(window); ref.step(window)
+        for e in halves:
+            e.Step(window)
+        whole.reduce_moments()
+        m_whole = whole.read_moments()
+        whole.apply_moments()
+        m_sum = _exchange(torch, halves)
+        m_ref = ref.reduce_moments(); ref.apply_moments(m_ref)
+        assert np.array_equal(m_sum, m_whole) and np.array_equal(m_whole, m_ref), f"window {w}: moments"
+        for e in halves:
+            assert np.array_equal(e.decomposition, whole.decomposition)
+            assert np.array_equal(e.GetEstimatedCenter(), whole.GetEstimatedCenter())
+    for e in [whole] + halves:
+        e.Step(3)
+    x = whole.GetAccepted()
+    assert np.array_equal(x[:, : n // 2], halves[0].GetAccepted())
+    assert np.array_equal(x[:, n // 2:], halves[1].GetAccepted())
+    assert np.array_equal(whole.lane("sigma")[n // 2:], halves[1].lane("sigma"))
+    ref.step(3)
+    assert np.array_equal(x, ref.x)
+
+
+@pytest.mark.parametrize("exact", [True, False])
+def test_sharded_exchange_d500(gpu, oracle, exact):
+    """Config 4's shape (D = 500, pooled, exchange every window) with two shards on one GPU, each shard bit for bit
+    its oracle ensemble fed with the same summed moments."""
+    import torch
+    dim, n, window = 500, 128, 5
+    pairs = [_pair(gpu, oracle, dim, n, 0, gpu.MODE_POOLED, exact, offset=k * n, stride=2) for k in range(2)]
+    for e, o in pairs:
+        assert e.Start(np.zeros(dim)) and o.start(np.zeros(dim))
+    for w in range(2):
+        for e, o in pairs:
+            e.Step(window); o.step(window)
+            _same(e, o, f"window {w}")
+        m_cpu = [o.reduce_moments() for _, o in pairs]
+        total = _exchange(torch, [e for e, _ in pairs])
+        assert np.array_equal(total, m_cpu[0] + m_cpu[1]), f"window {w}: summed moments"
+        for (e, o) in pairs:
+            o.apply_moments(total)
+            _same_shared(e, o, f"window {w}")
+    assert np.array_equal(pairs[0][0].decomposition, pairs[1][0].decomposition)
+    for e, o in pairs:
+        e.Step(2); o.step(2)
+        _same(e, o, "after the last exchange")
+    assert not np.array_equal(pairs[0][0].GetAccepted(), pairs[1][0].GetAccepted())   # different chains
+
+
+# ---------------------------------------------------------------- UpdateProposal's ladder
+def _broken_covariance(dim, rung):
+    """A covariance that drives UpdateProposal down to the given rung of TSimpleMCMC.H:1134-1389."""
+    c = np.eye(dim)
+    if rung == 1:                         # conditioning repairs it: a correlation > 1, an infinite and a NaN term
+        c[0, 1] = c[1, 0] = 1.5           # (a non-finite VARIANCE makes the trace, and with it sigma, NaN for good
+        c[2, 4] = c[4, 2] = np.nan        #  in the reference as well: TSimpleMCMC.H:1024, 1042)
+        c[0, 3] = c[3, 0] = np.inf
+    elif rung == 2:                       # |correlations| < maximum but not positive definite: eigen-decomposition
+        for i, j in ((0, 1), (0, 2), (1, 2)):
+            c[i, j] = c[j, i] = -0.9
+    elif rung == 3:                       # the same, so small that the eigenvalue sum fails its 1E-6 cut: shrink
+        for i, j in ((0, 1), (0, 2), (1, 2)):
+            c[i, j] = c[j, i] = -0.9
+        c *= 1e-9
+    else:
+        # The last rung needs an input the shrink cannot rescue (ten shrinks take every correlation down by
+        # 0.84^55, which makes any matrix of D <= 512 positive definite): three variances next to DBL_MAX whose
+        # emergency increment overflows.  The trace is infinite, so sigma goes to zero (TSimpleMCMC.H:1042) and
+        # ResetProposal puts it back to sqrt(1/D) (:1408-1410).
+        big = 1.7976e308
+        for i in range(3):
+            c[i, i] = big
+            for j in range(i):
+                c[i, j] = c[j, i] = -0.5 * big
+    return c
+
+
+@pytest.mark.parametrize("mode", ["frozen", "pooled"])
+@pytest.mark.parametrize("dim,nchains", [(6, 70), (40, 64), (100, 70)])
+@pytest.mark.parametrize("rung", [1, 2, 3, 4])
+def test_update_proposal_ladder(gpu, oracle, rung, dim, nchains, mode):
+    m = gpu.MODE_FROZEN if mode == "frozen" else gpu.MODE_POOLED
+    e, o = _pair(gpu, oracle, dim, nchains, 0, m, True)
+    assert e.Start(np.zeros(dim)) and o.start(np.zeros(dim))
+    e.Step(7); o.step(7)
+    if mode == "pooled":
+        e.sync(); o.sync()
+    cov = _broken_covariance(dim, rung)
+    e.SetCovariance(cov); o.set_covariance(cov)
+    e.UpdateProposal(); o.update_proposal()
+    assert e.get_param("LAST_UPDATE_PATH") == rung
+    _same_shared(e, o, f"rung {rung}")
+    _same(e, o, f"rung {rung}, after the update")
+    u = e.decomposition
+    if rung == 2:
+        assert np.abs(np.tril(u, -1)).max() > 0          # a full matrix: the FULLU kernels run from here
+    else:
+        assert np.abs(np.tril(u, -1)).max() == 0
+    if rung == 4:
+        assert np.all(e.lane("trials") == 0) and np.array_equal(e.covariance, np.eye(dim))
+        assert np.all(e.lane("sigma") == np.sqrt(1.0 / dim))
+    for k in range(2):
+        e.Step(25); o.step(25)
+        _same(e, o, f"rung {rung}, {25 * (k + 1)} steps later")
+        if mode == "pooled":
+            e.sync(); o.sync()
+            _same_shared(e, o, f"rung {rung}, sync {k}")
+    assert e.lane("naccept").sum() > 0
+
+
+@pytest.mark.parametrize("dim,nchains", [(6, 70), (100, 64)])
+def test_user_correlations_that_fail_cholesky(gpu, oracle, dim, nchains):
+    """SetCorrelation hints (TSimpleMCMC.H:883-904) that are not positive definite: Start's ResetProposal goes down
+    the ladder to the eigen-decomposition (the IMPOSE_RANDOM_CORRELATIONS experiment of SimpleMCMC.C:107-115)."""
+    e, o = _pair(gpu, oracle, dim, nchains, 0, gpu.MODE_FROZEN, True)
+    for i, j, c in ((0, 1, -0.9), (0, 2, -0.9), (1, 2, -0.9), (3, 4, 5.0)):
+        e.SetCorrelation(i, j, c); o.set_correlation(i, j, c)
+    assert e.Start(np.zeros(dim)) and o.start(np.zeros(dim))
+    assert e.get_param("LAST_UPDATE_PATH") == 2
+    _same_shared(e, o, "after start")
+    e.Step(50); o.step(50)
+    _same(e, o, "50 steps on the full decomposition")
+
+
+# ---------------------------------------------------------------- ResetProposal in the middle of a run
+@pytest.mark.parametrize("mode", ["frozen", "pooled"])
+@pytest.mark.parametrize("dim,nchains", [(5, 70), (50, 128), (120, 64)])
+def test_reset_proposal_after_steps(gpu, oracle, dim, nchains, mode):
+    """SimpleMCMC.C:183: burn-in steps, ResetProposal(), more steps."""
+    m = gpu.MODE_FROZEN if mode == "frozen" else gpu.MODE_POOLED
+    e, o = _pair(gpu, oracle, dim, nchains, 0, m, True)
+    e.SetGaussian(1, 0.5); o.set_gaussian(1, 0.5)
+    start = np.linspace(-0.2, 0.3, dim)
+    assert e.Start(start) and o.start(start)
+    for _ in range(2):
+        e.Step(20); o.step(20)
+        if mode == "pooled":
+            e.sync(); o.sync()
+    e.ResetProposal(); o.reset_proposal()
+    _same_shared(e, o, "after the reset")
+    _same(e, o, "after the reset")
+    assert np.all(e.lane("trials") == 0) and np.all(e.lane("successes") == 0)
+    assert np.array_equal(e.GetEstimatedCenter(), e.GetAccepted()[:, 0])       # fCentralPoint = fLastPoint (:1484)
+    for k in range(2):
+        e.Step(20); o.step(20)
+        _same(e, o, f"{20 * (k + 1)} steps after the reset")
+        if mode == "pooled":
+            e.sync(); o.sync()
+            _same_shared(e, o, f"sync {k} after the reset")

@@ -229,8 +229,32 @@ def test_pooled_iso_matches_oracle(gpu, oracle, dim, nchains, window, nwin, exac
         assert np.array_equal(e.covariance, o.covariance)
         assert np.array_equal(e.GetEstimatedCenter(), o.center)
         assert np.array_equal(e.decomposition, o.decomposition)
+        # UpdateProposal's sigma rescale and acceptance de-weighting (TSimpleMCMC.H:1042-1043, 1081-1086) are in the
+        # chains' columns as soon as the update returns: what SaveStep would write is what the reference holds
+        _assert_same_state(e, o, f"window {w}, after the update")
+        assert e.saved_state(chain=1)["sigma"] == o.lane("sigma")[1] == e.GetSigma(chain=1)
     e.Step(3); o.step(3)
     _assert_same_state(e, o, "after the last sync")
+
+
+def test_set_sigma_after_an_update_is_not_rescaled(gpu):
+    """SetSigma after UpdateProposal replaces the rescaled value (TSimpleMCMC.H:775); two updates in a row rescale twice."""
+    e = gpu.Engine(6, 70)
+    assert e.Start(np.zeros(6))
+    e.Step(40); e.sync()
+    e.SetSigma(0.125)
+    assert np.all(e.lane("sigma") == 0.125)
+    e.Step(1)
+    assert np.all(np.abs(e.lane("sigma") / 0.125 - 1.0) < 0.01)        # one step of the 1/500 power law, no stale factor
+    e.Step(30); e.reduce_moments(); e.apply_moments()
+    before = e.lane("sigma").copy()
+    cov = e.covariance
+    e.SetCovariance(cov * 4.0)
+    e.UpdateProposal()                                                   # trace x 4: sigma halves
+    assert np.array_equal(e.lane("sigma"), before * 0.5)
+    e.SetCovariance(cov)
+    e.UpdateProposal()
+    assert np.array_equal(e.lane("sigma"), before * 0.5 * 2.0)
 
 
 def test_pooled_split_launches_equal_one_launch(gpu):

@@ -38,8 +38,17 @@ void RunSteps(MCMC& mcmc, int steps, int window, bool saveLast) {
 int SimpleMCMC(int cycles, int steps, const char* outputName, int dim, int chains, const char* restoreName) {
     std::cout << "Simple MCMC (MI355X engine) D=" << dim << " chains=" << chains << std::endl;
     sMCMC::TreeType tree("SimpleMCMC", "Tree of accepted points");
-    sMCMC::TSimpleMCMC<sMCMC::TDummyLogLikelihood> mcmc(&tree, true);
-    sMCMC::TDummyLogLikelihood& like = mcmc.GetLogLikelihood();
+    // the likelihood is chosen at compile time, as SimpleMCMC.C:5-39 does: the README's isotropic Gaussian by
+    // default, -DUSE_HEADER_TDUMMY for the quadratic form of TDummyLogLikelihood.H, -DUSE_HARD_LIKELIHOOD for Rosenbrock
+#if defined(USE_HEADER_TDUMMY)
+    typedef sMCMC::TDummyLogLikelihood Likelihood;
+#elif defined(USE_HARD_LIKELIHOOD)
+    typedef sMCMC::THardLogLikelihood Likelihood;
+#else
+    typedef sMCMC::TIsoGaussLogLikelihood Likelihood;
+#endif
+    sMCMC::TSimpleMCMC<Likelihood> mcmc(&tree, true);
+    Likelihood& like = mcmc.GetLogLikelihood();
     like.SetDim(dim);
     like.Init();
     mcmc.SetChains(chains);

@@ -81,6 +81,8 @@ typedef enum {
     SMCMC_P_EXACT_ARITHMETIC = 17,      /* 1: reference operation order (default); 0: fused multiply-add */
     SMCMC_P_MOMENT_STRIDE = 18,         /* POOLED, dim > 63: fold the current point into the pooled moments every n-th step (default 1) */
     SMCMC_P_MOMENT_GROUP = 19,          /* chains per moment group (read only: 64, or the slice size of the dim > 63 path) */
+    SMCMC_P_KEEP_PROPOSED = 20,         /* 1: every launch leaves the proposal of its last step on the device for
+                                           smcmc_read_proposed (fProposed / GetProposed, TSimpleMCMC.H:514, 576); default 0 */
     SMCMC_P_COUNT_
 } smcmc_param;
 
@@ -195,6 +197,18 @@ int smcmc_export_moments(smcmc_engine* h, double* dst_device);
 int smcmc_import_moments(smcmc_engine* h, const double* src_device);
 int smcmc_apply_moments(smcmc_engine* h);
 int smcmc_sync(smcmc_engine* h);
+/* Native exchange for callers without torch.distributed (the C++ mirror): one RCCL communicator per engine,
+ * one rank per GPU.  Rank 0 makes the id (SMCMC_COMM_ID_BYTES bytes, an ncclUniqueId) and hands it to the
+ * other ranks by its own means (file, socket, MPI); every rank then calls smcmc_comm_init, which blocks until
+ * all nranks have arrived.  With a communicator attached smcmc_sync is reduce + ncclAllReduce(sum, f64) of M
+ * on the engine's stream + apply (the one collective of the path), and
+ * smcmc_allreduce_moments is the middle step on its own.  RCCL is loaded at the first call (dlopen), so the
+ * library has no link-time dependency on it; SMCMC_ERR_UNSUPPORTED when it cannot be loaded. */
+#define SMCMC_COMM_ID_BYTES 128
+int smcmc_comm_unique_id(void* id_out);
+int smcmc_comm_init(smcmc_engine* h, const void* id, int rank, int nranks);
+int smcmc_comm_destroy(smcmc_engine* h);
+int smcmc_allreduce_moments(smcmc_engine* h);
 int smcmc_update_proposal(smcmc_engine* h);   /* UpdateProposal() :1009 on the shared proposal */
 int smcmc_reset_proposal(smcmc_engine* h);    /* ResetProposal()  :1396 */
 
@@ -202,6 +216,9 @@ int smcmc_reset_proposal(smcmc_engine* h);    /* ResetProposal()  :1396 */
 int smcmc_nchains_padded(const smcmc_engine* h);          /* nchains rounded up to 64 */
 int smcmc_dim_padded(const smcmc_engine* h);              /* rows of the device state: the kernel family's register-array size */
 int smcmc_read_state(smcmc_engine* h, double* x, double* logl);   /* GetAccepted :502, x[dim][nchains] */
+/* GetProposed :514, x[dim][nchains]: the point the latest step proposed (after Start / Restore: the start point).
+ * Needs SMCMC_P_KEEP_PROPOSED = 1 (SMCMC_ERR_LOGIC otherwise). */
+int smcmc_read_proposed(smcmc_engine* h, double* x);
 int smcmc_read_lane_f64(smcmc_engine* h, int field, double* out);
 int smcmc_read_lane_i32(smcmc_engine* h, int field, int32_t* out);
 int smcmc_read_moments(smcmc_engine* h, double* out);     /* host copy of M */

@@ -18,7 +18,7 @@ MODE_FROZEN, MODE_POOLED = 0, 1
 PARAMS = ["COVARIANCE_WINDOW", "COVARIANCE_DEWEIGHT", "ACCEPTANCE_WINDOW", "ACCEPTANCE_DEWEIGHT",
           "ACCEPTANCE_RIGIDITY", "TARGET_ACCEPTANCE", "SIGMA", "MAXIMUM_CORRELATION", "STEP_RMS_WINDOW",
           "NEXT_UPDATE", "COVARIANCE_TRIALS", "CENTER_TRIALS", "COVARIANCE_TRACE", "TOTAL_STEPS",
-          "SIGMA_TRACE", "UPDATE_COUNT", "LAST_UPDATE_PATH", "EXACT_ARITHMETIC", "MOMENT_STRIDE", "MOMENT_GROUP"]
+          "SIGMA_TRACE", "UPDATE_COUNT", "LAST_UPDATE_PATH", "EXACT_ARITHMETIC", "MOMENT_STRIDE", "MOMENT_GROUP", "KEEP_PROPOSED"]
 P = {name: i for i, name in enumerate(PARAMS)}
 LANE_F64 = {name: i for i, name in enumerate(
     ["logl", "sigma", "acceptance", "acceptance_trials", "rigidity", "last_value", "last_x0", "step_rms",
@@ -69,11 +69,16 @@ SIGNATURES = {
     "smcmc_import_moments": (C.c_int, [_H, C.c_void_p]),
     "smcmc_apply_moments": (C.c_int, [_H]),
     "smcmc_sync": (C.c_int, [_H]),
+    "smcmc_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "smcmc_comm_init": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_int]),
+    "smcmc_comm_destroy": (C.c_int, [_H]),
+    "smcmc_allreduce_moments": (C.c_int, [_H]),
     "smcmc_update_proposal": (C.c_int, [_H]),
     "smcmc_reset_proposal": (C.c_int, [_H]),
     "smcmc_nchains_padded": (C.c_int, [_H]),
     "smcmc_dim_padded": (C.c_int, [_H]),
     "smcmc_read_state": (C.c_int, [_H, _dp, _dp]),
+    "smcmc_read_proposed": (C.c_int, [_H, _dp]),
     "smcmc_read_lane_f64": (C.c_int, [_H, C.c_int, _dp]),
     "smcmc_read_lane_i32": (C.c_int, [_H, C.c_int, _ip]),
     "smcmc_read_moments": (C.c_int, [_H, _dp]),
@@ -105,6 +110,7 @@ SIGNATURES = {
                                              C.c_void_p]),
 }
 AUTOCORR_LAGS = 64
+COMM_ID_BYTES = 128
 
 _lib = None
 _libs = {}

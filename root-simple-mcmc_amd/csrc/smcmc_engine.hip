@@ -5,6 +5,8 @@
 // launch logic.  There is no CPU execution path: every entry point that needs
 // the device fails with SMCMC_ERR_NO_DEVICE / SMCMC_ERR_HIP when it is missing.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types only: the functions are looked up at run time (rccl_api)
 
 #include <cmath>
 #include <cstdio>
@@ -38,7 +40,7 @@ int pick_dp(int dim) {
 
 hipError_t dispatch_step(int dp, const StepParams& p, int like, bool exact, bool fullu, bool moments,
                          hipStream_t s) {
-    const bool special = p.scan_dim >= 0 || p.uniform_mask != 0;
+    const bool special = p.scan_dim >= 0 || p.uniform_mask != 0 || p.proposed != nullptr;
     switch (dp) {
 #define SMCMC_DP_CASE(n) case n: return launch_step<n>(p, like, exact, fullu, moments, special, s);
         SMCMC_FOR_EACH_DP(SMCMC_DP_CASE)
@@ -92,6 +94,10 @@ struct smcmc_engine {
     double* d_moments = nullptr;
     double* d_chunks = nullptr;
     double* d_forced = nullptr;
+    ncclComm_t comm = nullptr;     // smcmc_comm_init
+    int comm_ranks = 0;
+    double* d_proposed = nullptr;  // [dp][npad], allocated by SMCMC_P_KEEP_PROPOSED
+    bool keep_proposed = false;
     double* d_uniform = nullptr;   // [2][dp] bounds of the uniform dimensions
     int scan_dim = -1;             // fScanDimension
     std::string error;
@@ -395,6 +401,7 @@ StepParams make_params(smcmc_engine* h, int nsteps, int metropolis) {
     p.x = h->d_x; p.lane_f64 = h->d_lane_f64; p.lane_i32 = h->d_lane_i32;
     p.gacc = h->d_gacc;
     p.save_x = nullptr; p.save_logl = nullptr; p.save_stride = 1;
+    p.proposed = h->keep_proposed ? h->d_proposed : nullptr;
     p.uniform = h->d_uniform;
     for (int d = 0; d < h->dim && d < 64; ++d)   // the register kernels (dim <= 63); larger dimensions carry theirs in d_uniform
         if (P.ptype[d] == 1) p.uniform_mask |= (uint64_t)1 << d;
@@ -436,13 +443,16 @@ int launch(smcmc_engine* h, int nsteps, int metropolis, int stride, double* save
         q.x = p.x; q.lane_f64 = p.lane_f64; q.lane_i32 = p.lane_i32;
         q.save_stride = 1;
         q.has_forced = p.has_forced; q.forced = p.forced;
+        q.proposed = p.proposed;
         q.uniform = p.uniform; q.scan_dim = p.scan_dim; q.scan_uniform = p.scan_uniform;
         q.scan_a = p.scan_a; q.scan_b = p.scan_b;
         for (int d = 0; d < h->dim; ++d)
             if (h->prop->ptype[d] == 1) q.special = 1;
         if (p.scan_dim >= 0) q.special = 1;
         const bool exact = h->exact || h->prop->decompFull;
-        if (q.special && !exact)
+        const bool special_proposal = q.special != 0;
+        if (exact && q.proposed != nullptr) q.special = 1;   // the SPECIAL instantiation also stores the proposal
+        if (special_proposal && !exact)
             return fail(h, SMCMC_ERR_UNSUPPORTED,
                         "uniform proposals and the scan of a dimension run in reference-order arithmetic only");
         if (exact && h->likelihood == SMCMC_LIKE_QUADFORM)
@@ -488,6 +498,8 @@ int launch(smcmc_engine* h, int nsteps, int metropolis, int stride, double* save
     const bool moments = (h->mode == SMCMC_MODE_POOLED);
     const bool fullu = h->prop->decompFull;
     const bool exact = h->exact || fullu;   // the full (eigen) decomposition only exists in reference order
+    if (p.proposed != nullptr && !exact)
+        return fail(h, SMCMC_ERR_UNSUPPORTED, "the proposed point is kept in reference-order arithmetic only for dim <= 63");
     if ((p.scan_dim >= 0 || p.uniform_mask != 0) && !exact)
         return fail(h, SMCMC_ERR_UNSUPPORTED,
                     "uniform proposals and the scan of a dimension run in reference-order arithmetic only");
@@ -590,9 +602,10 @@ int smcmc_create(int dim, int nchains, int likelihood, uint64_t seed, uint32_t c
 
 int smcmc_destroy(smcmc_engine* h) {
     if (!h) return SMCMC_OK;
+    (void)smcmc_comm_destroy(h);
     ON_DEVICE(h);
     if (h->d_x) (void)hipStreamSynchronize(h->stream);
-    (void)hipFree(h->d_x); (void)hipFree(h->d_forced); (void)hipFree(h->d_uniform); (void)hipFree(h->d_lane_f64); (void)hipFree(h->d_lane_i32);
+    (void)hipFree(h->d_x); (void)hipFree(h->d_forced); (void)hipFree(h->d_proposed); (void)hipFree(h->d_uniform); (void)hipFree(h->d_lane_f64); (void)hipFree(h->d_lane_i32);
     (void)hipFree(h->d_U); (void)hipFree(h->d_Uop); (void)hipFree(h->d_like); (void)hipFree(h->d_c0); (void)hipFree(h->d_gacc);
     (void)hipFree(h->d_moments); (void)hipFree(h->d_chunks);
     delete h->prop;
@@ -713,6 +726,15 @@ int smcmc_set_param(smcmc_engine* h, int which, double v) {
                 return upload_shared(h);
             }
             return SMCMC_OK;
+        case SMCMC_P_KEEP_PROPOSED:
+            if (v != 0.0 && !h->d_proposed) {
+                const size_t bytes = sizeof(double) * (size_t)h->npad * h->dp;
+                HIP_TRY(h, hipMalloc(&h->d_proposed, bytes));
+                // before the first step the proposed point is the start point (TSimpleMCMC.H:250-253)
+                HIP_TRY(h, hipMemcpyAsync(h->d_proposed, h->d_x, bytes, hipMemcpyDeviceToDevice, h->stream));
+            }
+            h->keep_proposed = (v != 0.0);
+            return SMCMC_OK;
         case SMCMC_P_MOMENT_STRIDE:
             if (v < 1.0) return fail(h, SMCMC_ERR_INVALID, "moment stride must be >= 1");
             if (!h->panel_w && v != 1.0)
@@ -754,6 +776,7 @@ int smcmc_get_param(smcmc_engine* h, int which, double* out) {
         case SMCMC_P_EXACT_ARITHMETIC: *out = h->exact ? 1.0 : 0.0; break;
         case SMCMC_P_MOMENT_STRIDE: *out = h->moment_stride; break;
         case SMCMC_P_MOMENT_GROUP: *out = h->panel_w ? h->slice_chains : kWave; break;
+        case SMCMC_P_KEEP_PROPOSED: *out = h->keep_proposed ? 1.0 : 0.0; break;
         default: return fail(h, SMCMC_ERR_INVALID, "unknown parameter");
     }
     return SMCMC_OK;
@@ -772,6 +795,8 @@ static int place_chains(smcmc_engine* h, const double* x0, int broadcast, std::v
     for (int d = 0; d < D; ++d)
         for (int c = 0; c < N; ++c) x[(size_t)d * NP + c] = broadcast ? x0[d] : x0[(size_t)d * N + c];
     HIP_TRY(h, hipMemcpyAsync(h->d_x, x.data(), x.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (h->d_proposed)   // fProposed = start (TSimpleMCMC.H:250-253, 326-329)
+        HIP_TRY(h, hipMemcpyAsync(h->d_proposed, x.data(), x.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
 
     // Start's likelihood call (TSimpleMCMC.H:258): a scan step (metropolis == 2) that is
     // forced to the start point evaluates and stores logL(start) for every chain
@@ -999,7 +1024,95 @@ int smcmc_apply_moments(smcmc_engine* h) {
 int smcmc_sync(smcmc_engine* h) {
     int st = smcmc_reduce_moments(h);
     if (st) return st;
+    if (h->comm) {
+        st = smcmc_allreduce_moments(h);
+        if (st) return st;
+    }
     return smcmc_apply_moments(h);
+}
+
+// ---- RCCL, looked up at run time ---------------------------------------------------------------
+namespace {
+struct RcclApi {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    bool ok = false;
+};
+RcclApi& rccl_api() {
+    static RcclApi api = [] {
+        RcclApi a;
+        // a copy the process has already loaded (PyTorch ships one) wins over a second one
+        const char* names[] = {"librccl.so", "librccl.so.1"};
+        for (const char* n : names)
+            if (!a.lib) a.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
+        for (const char* n : names)
+            if (!a.lib) a.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        if (!a.lib) a.lib = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!a.lib) return a;
+        a.GetUniqueId = (decltype(a.GetUniqueId))dlsym(a.lib, "ncclGetUniqueId");
+        a.CommInitRank = (decltype(a.CommInitRank))dlsym(a.lib, "ncclCommInitRank");
+        a.CommDestroy = (decltype(a.CommDestroy))dlsym(a.lib, "ncclCommDestroy");
+        a.AllReduce = (decltype(a.AllReduce))dlsym(a.lib, "ncclAllReduce");
+        a.GetErrorString = (decltype(a.GetErrorString))dlsym(a.lib, "ncclGetErrorString");
+        a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.AllReduce && a.GetErrorString;
+        return a;
+    }();
+    return api;
+}
+}  // namespace
+
+int smcmc_comm_unique_id(void* id_out) {
+    if (!id_out) return SMCMC_ERR_INVALID;
+    static_assert(sizeof(ncclUniqueId) == SMCMC_COMM_ID_BYTES, "SMCMC_COMM_ID_BYTES must be the size of an ncclUniqueId");
+    RcclApi& api = rccl_api();
+    if (!api.ok) return SMCMC_ERR_UNSUPPORTED;
+    ncclUniqueId id;
+    if (api.GetUniqueId(&id) != ncclSuccess) return SMCMC_ERR_RUNTIME;
+    std::memcpy(id_out, &id, sizeof(id));
+    return SMCMC_OK;
+}
+
+int smcmc_comm_init(smcmc_engine* h, const void* id, int rank, int nranks) {
+    if (!h || !id || nranks < 1 || rank < 0 || rank >= nranks) return SMCMC_ERR_INVALID;
+    if (h->comm) return fail(h, SMCMC_ERR_LOGIC, "the engine already has a communicator");
+    RcclApi& api = rccl_api();
+    if (!api.ok) return fail(h, SMCMC_ERR_UNSUPPORTED, "librccl.so could not be loaded");
+    ON_DEVICE(h);
+    ncclUniqueId uid;
+    std::memcpy(&uid, id, sizeof(uid));
+    const ncclResult_t r = api.CommInitRank(&h->comm, nranks, uid, rank);
+    if (r != ncclSuccess) {
+        h->comm = nullptr;
+        return fail(h, SMCMC_ERR_RUNTIME, std::string("ncclCommInitRank: ") + api.GetErrorString(r));
+    }
+    h->comm_ranks = nranks;
+    return SMCMC_OK;
+}
+
+int smcmc_comm_destroy(smcmc_engine* h) {
+    if (!h) return SMCMC_ERR_INVALID;
+    if (!h->comm) return SMCMC_OK;
+    ON_DEVICE(h);
+    (void)hipStreamSynchronize(h->stream);
+    rccl_api().CommDestroy(h->comm);
+    h->comm = nullptr;
+    h->comm_ranks = 0;
+    return SMCMC_OK;
+}
+
+// sum of the packed moment vector M over the ranks, in place, on the engine's stream
+int smcmc_allreduce_moments(smcmc_engine* h) {
+    if (!h || !h->started) return SMCMC_ERR_INVALID;
+    if (!h->comm) return fail(h, SMCMC_ERR_LOGIC, "no communicator: smcmc_comm_init first");
+    ON_DEVICE(h);
+    RcclApi& api = rccl_api();
+    const ncclResult_t r = api.AllReduce(h->d_moments, h->d_moments, npacked(h), ncclDouble, ncclSum, h->comm, h->stream);
+    if (r != ncclSuccess) return fail(h, SMCMC_ERR_RUNTIME, std::string("ncclAllReduce: ") + api.GetErrorString(r));
+    return SMCMC_OK;
 }
 
 int smcmc_update_proposal(smcmc_engine* h) {
@@ -1056,6 +1169,17 @@ int smcmc_read_state(smcmc_engine* h, double* x, double* logl) {
     }
     if (logl) HIP_TRY(h, hipMemcpy(logl, h->d_lane_f64 + (size_t)SMCMC_LANE_LOGL * NP, (size_t)N * sizeof(double),
                                    hipMemcpyDeviceToHost));
+    return SMCMC_OK;
+}
+
+int smcmc_read_proposed(smcmc_engine* h, double* x) {
+    if (!h || !x) return SMCMC_ERR_INVALID;
+    if (!h->keep_proposed || !h->d_proposed)
+        return fail(h, SMCMC_ERR_LOGIC, "the proposed point is not kept: set SMCMC_P_KEEP_PROPOSED first");
+    ON_DEVICE(h);
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipMemcpy2D(x, (size_t)h->nchains * sizeof(double), h->d_proposed, (size_t)h->npad * sizeof(double),
+                           (size_t)h->nchains * sizeof(double), (size_t)h->dim, hipMemcpyDeviceToHost));
     return SMCMC_OK;
 }
 

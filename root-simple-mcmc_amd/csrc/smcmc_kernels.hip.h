@@ -179,6 +179,8 @@ struct StepParams {
     int scan_dim;              // fScanDimension (TSimpleMCMC.H:685-704), -1 = off
     int scan_uniform;          // the scanned dimension has a uniform proposal
     double scan_a, scan_b;     // uniform: bounds; Gaussian: centre, sigma
+    double* proposed;          // optional [DP][npad]: the proposal of the launch's last step (fProposed, TSimpleMCMC.H:576);
+                               // only the SPECIAL instantiation looks at it
     int zero;                  // always 0; makes table addresses depend on the step so that the
                                // compiler does not hoist (and then spill) whole tables out of the loop
 };
@@ -255,8 +257,9 @@ __device__ __forceinline__ double loglike(const double (&p)[DP], cptr_f64 prm, i
     return logl;
 }
 
-// SPECIAL = the variant that also knows uniform per-dimension proposals and the scan of one
-// dimension (TSimpleMCMC.H:685-716); kept out of the common kernels, whose register allocation it disturbs.
+// SPECIAL = the variant that also knows uniform per-dimension proposals, the scan of one dimension
+// (TSimpleMCMC.H:685-716) and the read-back of the proposed point (:514); kept out of the common kernels, whose
+// register allocation it disturbs.
 // The quadratic form (TDummyLogLikelihood.H:24-28) of a point held in a column of LDS, xq[j * kXStride]:
 // the D^2-term running sum needs every p[j] for every i, which a register array can only give to fully
 // unrolled code (50 x 50 terms: minutes of compile time per kernel) -- a rolled outer loop indexes it
@@ -374,6 +377,13 @@ __global__ void __launch_bounds__(kWave, 2) step_kernel(const StepParams p) {
         // QUADFORM: the proposal and the accepted point trade places -- the likelihood reads the proposal from
         // the LDS column, the registers keep the accepted point to put back on a reject
         constexpr bool SWAP = (LIKE == SMCMC_LIKE_QUADFORM);
+        if constexpr (SPECIAL) {
+            // GetProposed() (TSimpleMCMC.H:514): the proposal of the latest step, accepted or not
+            if (p.proposed != nullptr && s + 1 == p.nsteps && active) {
+#pragma unroll
+                for (int d = 0; d < DP; ++d) p.proposed[(size_t)d * NP + chain] = xp[d];
+            }
+        }
         if constexpr (SWAP) {
 #pragma unroll
             for (int d = 0; d < DP; ++d) {

@@ -59,6 +59,8 @@ struct PanelParams {
     int scan_dim;             // fScanDimension (TSimpleMCMC.H:685-704), -1 = off
     int scan_uniform;         // the scanned dimension has a uniform proposal
     double scan_a, scan_b;    // uniform: bounds; Gaussian: centre, sigma
+    double* proposed;         // optional [dim][npad]: the proposal of the launch's last step (fProposed, TSimpleMCMC.H:576);
+                              // looked at by the SPECIAL instantiation and by the KEEP / FORCED ones of the matrix-pipe kernel
 };
 
 template <int W>
@@ -269,6 +271,17 @@ __global__ void __launch_bounds__(W * kWave) panel_step_kernel(const PanelParams
                         const double lo = p.uniform[ud], hi = p.uniform[D + ud];
                         place((int)ud, lo + (hi - lo) * smcmc_u01(smcmc_select_word(ublk, ud & 3u)));
                     }
+                }
+            }
+        }
+
+        if constexpr (SPECIAL) {
+            // GetProposed() (TSimpleMCMC.H:514): every wavefront stores its columns of the latest proposal
+            if (p.proposed != nullptr && s + 1 == p.nsteps && active) {
+#pragma unroll
+                for (int jl = 0; jl < CW; ++jl) {
+                    const int j = jl * W + w;
+                    if (j < D) p.proposed[(size_t)j * NP + chain] = xp[jl];
                 }
             }
         }

@@ -75,9 +75,11 @@ __device__ __forceinline__ void pm_contract(const double* __restrict__ a_ptr, co
 }
 
 // TI = 16-component tiles per wavefront: dim <= 128 TI
-// FORCED = the one-step instantiation that proposes the ForceStep point (kept out of the common kernel,
-// whose register allocation the extra paths disturb: 0.30 -> 0.37 ms/step at D=500)
-template <int TI, int LIKE, bool FORCED = false>
+// VARIANT: PM_PLAIN the common kernel; PM_FORCED the one-step instantiation that proposes the ForceStep point;
+// PM_KEEP the one that also stores the proposal of the launch's last step for GetProposed() (both kept out of
+// the common kernel, whose register allocation the extra paths disturb: 0.30 -> 0.37 ms/step at D=500)
+enum { PM_PLAIN = 0, PM_FORCED = 1, PM_KEEP = 2 };
+template <int TI, int LIKE, int VARIANT = PM_PLAIN>
 __global__ void __launch_bounds__(kPmW* kWave, 1) panel_mfma_kernel(const PanelParams p) {
     __shared__ double qs[16 * kPmW * TI * kPmCT];   // z[i][chain], later the published values of the ordered sums
     __shared__ double sig[kPmCT], x0s[kPmCT];
@@ -201,7 +203,7 @@ __global__ void __launch_bounds__(kPmW* kWave, 1) panel_mfma_kernel(const PanelP
         uint32_t uword = 0;
 
         // ForceStep (TSimpleMCMC.H:671-678): the proposal is the forced point, the proposal state is not updated
-        constexpr bool forced_now = FORCED;   // the engine launches the FORCED instantiation for that one step
+        constexpr bool forced_now = (VARIANT == PM_FORCED);   // the engine launches that instantiation for the one step
         if (summer && forced_now) {
             const uint32_t gid = p.chain_offset + (uint32_t)mychain;
             const smcmc_u32x4 ablk = smcmc_draw_block(p.seed, gid, step, aw >> 2, SMCMC_STREAM_STEP);
@@ -294,6 +296,21 @@ __global__ void __launch_bounds__(kPmW* kWave, 1) panel_mfma_kernel(const PanelP
                     xp[t][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0, xp[t][0], 0, 0, 0);
                     xp[t][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b1, xp[t][1], 0, 0, 0);
                 }
+            }
+        }
+
+        if constexpr (VARIANT != PM_PLAIN) {
+            // GetProposed() (TSimpleMCMC.H:514)
+            if (p.proposed != nullptr && s + 1 == p.nsteps) {
+#pragma unroll
+                for (int t = 0; t < TI; ++t)
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int i = comp(t, r), chain = base + 16 * ct + c;
+                            if (owns(t) && i < D && chain < p.nchains) p.proposed[(size_t)i * NP + chain] = xp[t][ct][r];
+                        }
             }
         }
 

@@ -219,6 +219,16 @@ class Engine:
         self._check(self._lib.smcmc_read_state(self._h, _ptr(x), None))
         return x
 
+    def KeepProposed(self, on=True):
+        """Leave the proposal of every launch's last step on the device for GetProposed()."""
+        self.set_param("KEEP_PROPOSED", 1.0 if on else 0.0)
+
+    def GetProposed(self):
+        """fProposed (TSimpleMCMC.H:514) of every chain, [dim][nchains]; needs KeepProposed()."""
+        x = np.zeros((self.dim, self.nchains))
+        self._check(self._lib.smcmc_read_proposed(self._h, _ptr(x)))
+        return x
+
     def GetAcceptedLogLikelihood(self):
         return self.lane("logl")
 
@@ -254,6 +264,25 @@ class Engine:
 
     def apply_moments(self):
         self._check(self._lib.smcmc_apply_moments(self._h))
+
+    # native RCCL communicator (include/smcmc.h): rank 0 makes the id, the caller hands it to the other ranks
+    @staticmethod
+    def comm_unique_id(library=None):
+        buf = C.create_string_buffer(_capi.COMM_ID_BYTES)
+        st = _capi.load(library).smcmc_comm_unique_id(buf)
+        if st != _capi.OK:
+            raise SmcmcError(st, "smcmc_comm_unique_id failed (is librccl.so loadable?)")
+        return buf.raw
+
+    def comm_init(self, unique_id, rank, nranks):
+        buf = C.create_string_buffer(bytes(unique_id), _capi.COMM_ID_BYTES)
+        self._check(self._lib.smcmc_comm_init(self._h, buf, int(rank), int(nranks)))
+
+    def comm_destroy(self):
+        self._check(self._lib.smcmc_comm_destroy(self._h))
+
+    def allreduce_moments(self):
+        self._check(self._lib.smcmc_allreduce_moments(self._h))
 
     def sync(self):
         self._check(self._lib.smcmc_sync(self._h))

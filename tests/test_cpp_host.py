@@ -163,3 +163,53 @@ def test_restore_walk_matches_the_reference(smcmc, tmp_path, randomize):
         assert int(trials) == 100 + n - 1           # the adaptive state always comes from the last entry (:1540-1570)
         lo, hi = map(float, lines[1].split())
         assert 0.0 < lo < 1e-3 and 1 - 1e-3 < hi < 1.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("metropolis", [0, 1])
+def test_step_column_matches_the_reference_chain(gpu, oracle, tmp_path, metropolis):
+    """The `Step` branch (fTrialStep = fProposed - fAccepted, TSimpleMCMC.H:391-396), `Accepted`, `LogLikelihood` and
+    the number of tree entries of Step(true, metropolis) against the CPU restatement: a rejected step still records
+    the step it tried, and Step(true, 1) writes no entry when it turns a downhill step away (:448)."""
+    exe = str(tmp_path / "step_column.exe")
+    cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-Werror", f"-I{os.path.join(ROOT, 'include')}",
+           os.path.join(ROOT, "tests", "cpp", "step_column.C"), f"-L{LIBDIR}", "-lsmcmc_amd",
+           f"-Wl,-rpath,{LIBDIR}", "-Wl,-rpath,/opt/rocm/lib", "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    dim, nsteps = 5, 120
+    out = tmp_path / "steps.csv"
+    r = subprocess.run([exe, str(dim), str(nsteps), str(metropolis), str(out)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = open(out).read().splitlines()
+    header = [h for h in lines[0].split(",")]
+    col = {h: i for i, h in enumerate(header) if h}
+    rows = [l.split(",") for l in lines[1:]]
+
+    c = oracle.Chain(dim, chain_id=0)
+    c.set_covariance_frozen(1)
+    start = np.full(dim, 0.25)
+    assert c.start(start)
+    want = [(start.copy(), start.copy(), c.scalars["accepted_logl"], 0)]       # Start(p, true): fTrialStep = start (:253)
+    moved = 0
+    for s in range(nsteps):
+        before = c.accepted
+        logl_before = c.scalars["accepted_logl"]
+        took = c.step(True, metropolis)
+        moved += int(took)
+        prop_logl = c.scalars["proposed_logl"]
+        soft_reject = (not took and np.isfinite(prop_logl) and not prop_logl < -0.999999E+30
+                       and prop_logl - logl_before < 0.0)
+        if metropolis == 1 and soft_reject:
+            continue                                                             # :448 returns before SaveStep
+        want.append((c.proposed - before, c.accepted, c.scalars["accepted_logl"], s + 1))
+    assert f"moved {moved} entries {len(want)}" in r.stdout
+    assert len(rows) == len(want)
+    for row, (step, acc, logl, total) in zip(rows, want):
+        got_step = np.array([float(row[col[f"Step[{k}]"]]) for k in range(dim)])
+        got_acc = np.array([float(row[col[f"Accepted[{k}]"]]) for k in range(dim)])
+        assert np.array_equal(got_step, step), (total, got_step, step)
+        assert np.array_equal(got_acc, acc)
+        assert float(row[col["LogLikelihood"]]) == logl and int(row[col["TotalSteps"]]) == total
+    rejected = [w for w in want[1:] if np.any(w[0] != 0) and w[3] > 0]
+    assert len(rejected) > 0

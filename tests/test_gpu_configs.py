@@ -280,3 +280,62 @@ def test_reset_proposal_after_steps(gpu, oracle, dim, nchains, mode):
         if mode == "pooled":
             e.sync(); o.sync()
             _same_shared(e, o, f"sync {k} after the reset")
+
+
+# ---------------------------------------------------------------- GetProposed
+@pytest.mark.parametrize("kind,dim,exact", [(0, 5, True), (1, 50, True), (2, 31, True), (0, 100, True), (2, 200, True),
+                                            (0, 100, False), (1, 300, False)])
+def test_get_proposed(gpu, oracle, kind, dim, exact):
+    """GetProposed() (TSimpleMCMC.H:514): the point the latest step proposed, whether or not it was taken."""
+    n = 70
+    prm = oracle.like_params(kind, dim)
+    prm = prm if prm.size else None
+    e = gpu.Engine(dim, n, likelihood=kind, likelihood_params=prm, mode=gpu.MODE_FROZEN, exact=exact)
+    x0 = np.full(dim, 0.9) if kind == 2 else np.full(dim, 0.01)
+    assert e.Start(x0)
+    e.KeepProposed()
+    assert np.array_equal(e.GetProposed(), np.repeat(x0[:, None], n, axis=1))     # fProposed = start (:250)
+    before = None
+    for nsteps in (1, 6):
+        e.Step(nsteps - 1) if nsteps > 1 else None
+        before = e.GetAccepted()
+        e.Step(1)
+        prop, acc, took = e.GetProposed(), e.GetAccepted(), e.lane("last_accept").astype(bool)
+        assert np.array_equal(prop[:, took], acc[:, took])                          # taken: accepted = proposed
+        assert np.array_equal(acc[:, ~took], before[:, ~took])
+        assert np.all(np.any(prop[:, ~took] != acc[:, ~took], axis=0))              # turned away: a different point
+    assert (~took).any() and (took.any() or kind != 0)     # (the stiff targets rarely move this early)
+    if exact and kind != 1:
+        for ch in (0, 69):
+            c = oracle.Chain(dim, kind=kind, params=prm, chain_id=ch)
+            c.set_covariance_frozen(1)
+            assert c.start(x0)
+            c.run_quiet(7)
+            assert np.array_equal(c.proposed, prop[:, ch])
+    forced = np.linspace(-0.1, 0.2, dim)
+    e.ForceStep(forced)
+    e.Step(1)
+    assert np.array_equal(e.GetProposed(), np.repeat(forced[:, None], n, axis=1))
+    e.KeepProposed(False)
+    with pytest.raises(gpu.SmcmcError):
+        e.GetProposed()
+
+
+def test_native_communicator_single_rank(gpu, oracle):
+    """smcmc_comm_init / smcmc_sync with an RCCL communicator of one rank: the all-reduce is the identity, so the
+    engine with a communicator equals the one without, bit for bit (more ranks need more GPUs than this box has)."""
+    dim, n = 20, 256
+    a, b = gpu.Engine(dim, n), gpu.Engine(dim, n)
+    assert a.Start(np.zeros(dim)) and b.Start(np.zeros(dim))
+    b.comm_init(gpu.Engine.comm_unique_id(), 0, 1)
+    for _ in range(3):
+        a.Step(10); b.Step(10)
+        a.sync(); b.sync()
+        assert np.array_equal(a.decomposition, b.decomposition)
+    b.reduce_moments(); b.allreduce_moments(); b.apply_moments()
+    a.reduce_moments(); a.apply_moments()
+    a.Step(3); b.Step(3)
+    assert np.array_equal(a.GetAccepted(), b.GetAccepted())
+    b.comm_destroy()
+    with pytest.raises(gpu.SmcmcError):
+        b.allreduce_moments()

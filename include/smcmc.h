@@ -231,14 +231,19 @@ int smcmc_get_decomposition(smcmc_engine* h, double* out);/* fDecomposition, dim
 int smcmc_state_device_ptr(smcmc_engine* h, double** x, double** logl);
 
 /* ---- Hamiltonian Monte Carlo (sMCMC::TSimpleHMC, reference TSimpleHMC.H:119-973) ------ */
-/* Every chain is an independent TSimpleHMC chain with the analytic gradient of the
- * device likelihood.  The HIP path runs the fixed-step configuration of the reference:
+/* Every chain is a TSimpleHMC chain with the analytic gradient of the device likelihood.
  * SetMeanEpsilon(negative value) keeps |epsilon| fixed (every update of fMeanEpsilon is
  * guarded by fMeanEpsilon > 0, TSimpleHMC.H:304-343, 833-846) and SetLeapFrog(n) fixes the
- * leapfrog count (:190, 302); smcmc_hmc_step returns SMCMC_ERR_UNSUPPORTED otherwise.
+ * leapfrog count (:190, 302): with both the chains are independent and a launch runs many
+ * steps.  Otherwise (the reference's default) the chains retune themselves, see
+ * smcmc_hmc_set_sync_interval.
  * Per-chain columns reuse smcmc_lane_f64 / smcmc_lane_i32: LOGL = -fAcceptedPotential,
  * LOGL_PROPOSED = -fProposedPotential, ACCEPTANCE = fCurrentAcceptance, TRIALS = fStepCount,
- * NACCEPT, LAST_ACCEPT. */
+ * NACCEPT, LAST_ACCEPT, and the SMCMC_HMC_LANE_* aliases below. */
+#define SMCMC_HMC_LANE_MEAN_EPSILON SMCMC_LANE_SIGMA          /* f64: fMeanEpsilon  (TSimpleHMC.H:888) */
+#define SMCMC_HMC_LANE_REVERSAL_LEN SMCMC_LANE_RIGIDITY       /* f64: fReversalLen  (:894) */
+#define SMCMC_HMC_LANE_LEAPFROG SMCMC_LANE_NEXT_UPDATE        /* i32: fLeapFrogSteps (:891) */
+#define SMCMC_HMC_LANE_CONTRIBUTES SMCMC_LANE_SUCCESSES       /* i32: the latest step fed UpdateCovariance (:336) */
 typedef struct smcmc_hmc smcmc_hmc;
 int smcmc_hmc_create(int dim, int nchains, int likelihood, uint64_t seed, uint32_t chain_offset, int device,
                      smcmc_hmc** out);                                   /* TSimpleHMC ctor :130 */
@@ -254,6 +259,22 @@ int smcmc_hmc_set_exact_arithmetic(smcmc_hmc* h, int exact);
 int smcmc_hmc_set_mean_epsilon(smcmc_hmc* h, double epsilon);            /* SetMeanEpsilon :181 (after Start, which resets it to 0.05) */
 int smcmc_hmc_get_mean_epsilon(smcmc_hmc* h, double* epsilon);           /* GetMeanEpsilon :184 */
 int smcmc_hmc_set_leapfrog(smcmc_hmc* h, int steps);                     /* SetLeapFrog :190 */
+int smcmc_hmc_get_leapfrog(smcmc_hmc* h, int* steps);                   /* fLeapFrogSteps of chain 0, signed as :190 keeps it */
+/* The covariance-driven tuning (UpdateCovariance :665-695, UpdateErrorMatrix :703-858) is pooled over the ensemble:
+ * every chain folds the point it stood on into moment groups of smcmc_hmc_moment_group() chains each step, and every
+ * `steps` steps (default 1) the pooled running covariance is brought up to date and UpdateErrorMatrix runs once; when
+ * it goes through, every chain takes the new step length and leapfrog count (:833-847).  One chain and an interval of
+ * one step is the reference chain.  Runs whenever the step length or the leapfrog count is not fixed;
+ * smcmc_hmc_set_track_covariance(h, 1) keeps it running for a fixed step too (the Trace / Orbit outputs). */
+int smcmc_hmc_set_sync_interval(smcmc_hmc* h, int steps);
+int smcmc_hmc_set_track_covariance(smcmc_hmc* h, int on);
+int smcmc_hmc_moment_group(const smcmc_hmc* h);
+int smcmc_hmc_sync(smcmc_hmc* h);                                        /* the pooled update now (end of a run) */
+/* out[10]: fCurrentCovarianceTrace, fEstimatedOrbitLength, updates that went through, fCovarianceTrials,
+ * fAveragePointTrials, fStepsRemaining, fStepsSinceUpdate, max scale, min scale, fEstimatedCovarianceTrace */
+int smcmc_hmc_get_tuning(smcmc_hmc* h, double* out);
+int smcmc_hmc_get_average_point(smcmc_hmc* h, double* out);              /* fAveragePoint [dim] */
+int smcmc_hmc_get_covariance(smcmc_hmc* h, double* out);                 /* GetEstimatedCovariance :197, dim*dim */
 int smcmc_hmc_start(smcmc_hmc* h, const double* x0, int broadcast);      /* Start :210-269 */
 int smcmc_hmc_step(smcmc_hmc* h, int nsteps);                            /* nsteps x Step(false) :279-401 */
 int smcmc_hmc_read_state(smcmc_hmc* h, double* q, double* momentum, double* logl);   /* fAccepted, fAcceptedMomentum */

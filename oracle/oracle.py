@@ -137,6 +137,29 @@ def _declare(L):
         f.restype = None
         f.argtypes = [C.c_void_p, _dp]
     L.oracle_hmc_gradient.argtypes = [C.c_int, C.c_int, _dp, _dp, _dp]
+    L.oracle_hmc_set_gradient_type.argtypes = [C.c_void_p, C.c_int]
+    for name in ("average", "covariance"):
+        f = getattr(L, "oracle_hmc_get_" + name)
+        f.restype = None
+        f.argtypes = [C.c_void_p, _dp]
+    L.oracle_hmc_ensemble_create.restype = C.c_void_p
+    L.oracle_hmc_ensemble_create.argtypes = [C.c_int, C.c_int, C.c_int, _dp, C.c_int, C.c_uint64, C.c_uint32, C.c_int,
+                                             C.c_int]
+    L.oracle_hmc_ensemble_destroy.argtypes = [C.c_void_p]
+    L.oracle_hmc_ensemble_chain.restype = C.c_void_p
+    L.oracle_hmc_ensemble_chain.argtypes = [C.c_void_p, C.c_int]
+    L.oracle_hmc_ensemble_configure.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_int]
+    L.oracle_hmc_ensemble_set_mean_epsilon.argtypes = [C.c_void_p, C.c_double]
+    L.oracle_hmc_ensemble_set_leapfrog.argtypes = [C.c_void_p, C.c_int]
+    L.oracle_hmc_ensemble_start.argtypes = [C.c_void_p, _dp, C.c_int]
+    L.oracle_hmc_ensemble_sync.argtypes = [C.c_void_p]
+    L.oracle_hmc_ensemble_step.argtypes = [C.c_void_p, C.c_int]
+    L.oracle_hmc_ensemble_get_state.argtypes = [C.c_void_p, _dp, _dp]
+    L.oracle_hmc_ensemble_get_lane.argtypes = [C.c_void_p, C.c_int, _dp]
+    for name in ("average", "covariance", "shared"):
+        f = getattr(L, "oracle_hmc_ensemble_get_" + name)
+        f.restype = None
+        f.argtypes = [C.c_void_p, _dp]
 
 
 def _p(a):
@@ -411,7 +434,9 @@ def loglike(kind, p, params=None):
 
 HMC_SCALARS = ["accepted_potential", "proposed_potential", "current_acceptance", "mean_epsilon",
                "leapfrog_steps", "step_count", "potential_count", "gradient_count", "last_accept",
-               "central_potential"]
+               "central_potential", "reversal_len", "trace", "orbit", "updates", "cov_trials"]
+HMC_SHARED = ["trace", "orbit", "updates", "cov_trials", "average_trials", "steps_remaining", "steps_since_update",
+              "max_scale", "min_scale", "est_trace"]
 
 
 class Hmc:
@@ -430,6 +455,7 @@ class Hmc:
             lib().oracle_hmc_destroy(self._h)
             self._h = None
 
+    def set_gradient_type(self, t): lib().oracle_hmc_set_gradient_type(self._h, int(t))
     def set_alpha(self, a): lib().oracle_hmc_set_alpha(self._h, a)
     def set_mean_epsilon(self, e): lib().oracle_hmc_set_mean_epsilon(self._h, e)
     def set_leapfrog(self, n): lib().oracle_hmc_set_leapfrog(self._h, n)
@@ -445,10 +471,64 @@ class Hmc:
     accepted = property(lambda self: self._vec("accepted", self.dim))
     momentum = property(lambda self: self._vec("momentum", self.dim))
     central = property(lambda self: self._vec("central", self.dim))
+    average = property(lambda self: self._vec("average", self.dim))
+    covariance = property(lambda self: self._vec("covariance", self.dim ** 2).reshape(self.dim, self.dim))
 
     @property
     def scalars(self):
         return dict(zip(HMC_SCALARS, self._vec("scalars", len(HMC_SCALARS))))
+
+
+class HmcEnsemble:
+    """The many-chain HMC engine's semantics on the CPU (oracle/hmc_oracle.c): per-chain reference chains whose
+    covariance-derived tuning (UpdateCovariance / UpdateErrorMatrix) is pooled over moment groups of `group` chains
+    every `sync_every` steps.  One chain, group 1, sync_every 1 is the reference chain."""
+
+    def __init__(self, nchains, dim, kind=LIKE_ISO, params=None, seed=20240607, chain_offset=0, group=64, sync_every=1,
+                 alpha=0.0, potential_from_gradient=False, fused_gradient=False, gradient_type=0):
+        self.nchains, self.dim = nchains, dim
+        prm = like_params(kind, dim, params)
+        self._h = lib().oracle_hmc_ensemble_create(nchains, dim, kind, _p(prm) if prm.size else None, prm.size, seed,
+                                                   chain_offset, group, sync_every)
+        lib().oracle_hmc_ensemble_configure(self._h, alpha, int(potential_from_gradient), int(fused_gradient),
+                                            int(gradient_type))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().oracle_hmc_ensemble_destroy(self._h)
+            self._h = None
+
+    def set_mean_epsilon(self, e): lib().oracle_hmc_ensemble_set_mean_epsilon(self._h, e)
+    def set_leapfrog(self, n): lib().oracle_hmc_ensemble_set_leapfrog(self._h, n)
+
+    def start(self, x0):
+        x0 = _f64(x0)
+        lib().oracle_hmc_ensemble_start(self._h, _p(x0), int(x0.ndim == 1))
+
+    def step(self, n=1): lib().oracle_hmc_ensemble_step(self._h, n)
+    def sync(self): lib().oracle_hmc_ensemble_sync(self._h)
+
+    def state(self):
+        q = np.zeros((self.dim, self.nchains)); m = np.zeros((self.dim, self.nchains))
+        lib().oracle_hmc_ensemble_get_state(self._h, _p(q), _p(m))
+        return q, m
+
+    def lane(self, name):
+        out = np.zeros(self.nchains)
+        lib().oracle_hmc_ensemble_get_lane(self._h, HMC_SCALARS.index(name), _p(out))
+        return out
+
+    def _vec(self, name, n):
+        out = np.zeros(n)
+        getattr(lib(), "oracle_hmc_ensemble_get_" + name)(self._h, _p(out))
+        return out
+
+    average = property(lambda self: self._vec("average", self.dim))
+    covariance = property(lambda self: self._vec("covariance", self.dim ** 2).reshape(self.dim, self.dim))
+
+    @property
+    def shared(self):
+        return dict(zip(HMC_SHARED, self._vec("shared", len(HMC_SHARED))))
 
 
 def hmc_gradient(kind, p, params=None):

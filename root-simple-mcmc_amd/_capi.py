@@ -25,6 +25,11 @@ LANE_F64 = {name: i for i, name in enumerate(
      "logl_proposed"])}
 LANE_I32 = {name: i for i, name in enumerate(
     ["trials", "successes", "next_update", "naccept", "step_rms_trials", "last_accept"])}
+# the HMC engine's aliases (SMCMC_HMC_LANE_* of include/smcmc.h)
+HMC_LANE_F64 = dict(LANE_F64, mean_epsilon=LANE_F64["sigma"], reversal_len=LANE_F64["rigidity"])
+HMC_LANE_I32 = dict(LANE_I32, leapfrog=LANE_I32["next_update"], contributes=LANE_I32["successes"])
+HMC_TUNING = ["trace", "orbit", "updates", "cov_trials", "average_trials", "steps_remaining", "steps_since_update",
+              "max_scale", "min_scale", "est_trace"]
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)
@@ -98,6 +103,14 @@ SIGNATURES = {
     "smcmc_hmc_set_mean_epsilon": (C.c_int, [_H, C.c_double]),
     "smcmc_hmc_get_mean_epsilon": (C.c_int, [_H, _dp]),
     "smcmc_hmc_set_leapfrog": (C.c_int, [_H, C.c_int]),
+    "smcmc_hmc_get_leapfrog": (C.c_int, [_H, C.POINTER(C.c_int)]),
+    "smcmc_hmc_set_sync_interval": (C.c_int, [_H, C.c_int]),
+    "smcmc_hmc_set_track_covariance": (C.c_int, [_H, C.c_int]),
+    "smcmc_hmc_moment_group": (C.c_int, [_H]),
+    "smcmc_hmc_sync": (C.c_int, [_H]),
+    "smcmc_hmc_get_tuning": (C.c_int, [_H, _dp]),
+    "smcmc_hmc_get_average_point": (C.c_int, [_H, _dp]),
+    "smcmc_hmc_get_covariance": (C.c_int, [_H, _dp]),
     "smcmc_hmc_start": (C.c_int, [_H, _dp, C.c_int]),
     "smcmc_hmc_step": (C.c_int, [_H, C.c_int]),
     "smcmc_hmc_read_state": (C.c_int, [_H, _dp, _dp, _dp]),

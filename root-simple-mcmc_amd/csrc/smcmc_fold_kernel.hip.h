@@ -39,9 +39,11 @@ constexpr int kFoldBT = 4;        // a wavefront folds a block of kFoldBT x kFol
 // workgroup: one workgroup per CU, one wavefront per SIMD -- single-wavefront workgroups stack up on a
 // few CUs instead and leave the rest idle.
 constexpr int kFoldWaves = 4;
+// mask (optional, [npad]): a chain with mask 0 folds nothing this time (the HMC engine: a step whose proposal had a
+// non-finite potential skips UpdateCovariance, TSimpleHMC.H:336)
 static __global__ void __launch_bounds__(kFoldWaves* kWave) fold_moments_kernel(const double* __restrict__ x, const double* __restrict__ c0,
                                                              int nchains, int npad, int D, int slice_chains,
-                                                             double* __restrict__ gacc) {
+                                                             double* __restrict__ gacc, const int32_t* __restrict__ mask) {
     constexpr int kS = 18;   // doubles per staged row: 16 chains + 2 (operand reads spread over the banks)
     __shared__ __attribute__((aligned(16))) double st_all[kFoldWaves][2 * kFoldBT][16][kS];
     __shared__ double occupancy_pad[1100];   // pushes the workgroup past 80 KB of LDS: one workgroup per CU
@@ -86,10 +88,13 @@ static __global__ void __launch_bounds__(kFoldWaves* kWave) fold_moments_kernel(
     typedef f64x2 stage_t[2 * kFoldBT][2];
     stage_t stA, stB;   // two stages of 16 chains in flight ahead of the matrix instructions
     auto fetch = [&](int c, stage_t& stage) {   // y = x - c0 (the constant 1 in row D, 0 above, 0 for chains past the ensemble)
+        const int chain = c + 4 * sq;
+        bool on[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) on[k] = (chain + k < nchains) && (mask == nullptr || mask[chain + k] != 0);
 #pragma unroll
         for (int op = 0; op < 2 * kFoldBT; ++op) {
             if (op >= nops) continue;
-            const int chain = c + 4 * sq;
             f64x2 v0 = {0.0, 0.0}, v1 = {0.0, 0.0};
             if (rr[op] < D) {
                 const f64x2* src = (const f64x2*)(x + (size_t)rr[op] * NP + chain);
@@ -99,10 +104,10 @@ static __global__ void __launch_bounds__(kFoldWaves* kWave) fold_moments_kernel(
             } else if (rr[op] == D) {
                 v0[0] = v0[1] = v1[0] = v1[1] = 1.0;
             }
-            if (chain + 0 >= nchains) v0[0] = 0.0;
-            if (chain + 1 >= nchains) v0[1] = 0.0;
-            if (chain + 2 >= nchains) v1[0] = 0.0;
-            if (chain + 3 >= nchains) v1[1] = 0.0;
+            if (!on[0]) v0[0] = 0.0;
+            if (!on[1]) v0[1] = 0.0;
+            if (!on[2]) v1[0] = 0.0;
+            if (!on[3]) v1[1] = 0.0;
             stage[op][0] = v0;
             stage[op][1] = v1;
         }
@@ -176,7 +181,7 @@ static __global__ void fold_reduce_kernel(const double* __restrict__ gacc, int n
 }
 
 hipError_t launch_fold(const double* x, const double* c0, int nchains, int npad, int D, int slice_chains, int nslices,
-                       double* gacc, hipStream_t stream);
+                       double* gacc, hipStream_t stream, const int32_t* mask = nullptr);
 hipError_t launch_fold_reduce(const double* gacc, int D, int nslices, double* moments, hipStream_t stream);
 
 }  // namespace smcmc

@@ -1,6 +1,13 @@
 // smcmc_hmc_engine.hip -- host engine behind the smcmc_hmc_* entry points of
 // include/smcmc.h: the many-chain form of sMCMC::TSimpleHMC (reference
-// TSimpleHMC.H:119-973) for a fixed step length and leapfrog count.
+// TSimpleHMC.H:119-973).  With a fixed step length and leapfrog count (SetMeanEpsilon(<0) +
+// SetLeapFrog(n)) the chains share nothing and a launch runs any number of steps.  Otherwise
+// (the reference's default) every chain retunes its own step length and leapfrog count as it
+// goes (:302-323, 342-344) and the covariance-driven retuning (:665-858) is pooled over the
+// ensemble: one step per launch, the accepted points folded into moment sums on the device
+// (smcmc_fold_kernel.hip.h), the pooled running covariance and UpdateErrorMatrix on the host
+// (smcmc_hmc_shared.hpp) every `sync_every` steps, the new step length / leapfrog count applied
+// per chain on the device.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -13,6 +20,8 @@
 #include "smcmc.h"
 #include "smcmc_hmc_kernel.hip.h"
 #include "smcmc_hmc_mfma_kernel.hip.h"
+#include "smcmc_fold_kernel.hip.h"
+#include "smcmc_hmc_shared.hpp"
 
 using namespace smcmc;
 
@@ -32,6 +41,12 @@ struct smcmc_hmc {
     double *d_q = nullptr, *d_pm = nullptr, *d_qn = nullptr, *d_pn = nullptr, *d_E = nullptr, *d_like = nullptr;
     double* d_lane_f64 = nullptr;
     int32_t* d_lane_i32 = nullptr;
+    // pooled tuning (adaptive step length / leapfrog count, or track_cov)
+    HmcShared* shared = nullptr;
+    bool track_cov = false;        // keep the running covariance even with a fixed step and count
+    int sync_every = 1, steps_in_window = 0;
+    int fold_nslices = 0, slice_chains = 0;
+    double *d_p0 = nullptr, *d_qprev = nullptr, *d_gacc = nullptr, *d_moments = nullptr, *d_zero = nullptr;
     std::string error;
 };
 
@@ -49,6 +64,59 @@ int hfail(smcmc_hmc* h, int status, const std::string& msg) {
             return hfail((h), SMCMC_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
+struct HmcDeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit HmcDeviceGuard(int device) {
+        if (hipGetDevice(&prev) == hipSuccess && prev != device) switched = (hipSetDevice(device) == hipSuccess);
+    }
+    ~HmcDeviceGuard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+    HmcDeviceGuard(const HmcDeviceGuard&) = delete;
+    HmcDeviceGuard& operator=(const HmcDeviceGuard&) = delete;
+};
+#define HMC_ON_DEVICE(h) HmcDeviceGuard device_guard_((h)->device)
+
+size_t hmc_npacked(const smcmc_hmc* h) { return (size_t)(h->dim + 1) * (h->dim + 2) / 2; }
+size_t hmc_gacc_doubles(const smcmc_hmc* h) {
+    const size_t T = (size_t)(h->dim + 1 + 15) / 16;
+    return (size_t)kFoldSlices * (T * (T + 1) / 2) * 4 * kWave;
+}
+
+// the chains retune themselves (TSimpleHMC.H:302-345, 833-847) unless both the step length and the count are fixed
+bool hmc_adaptive(const smcmc_hmc* h) { return h->mean_epsilon > 0.0 || h->leapfrog > 0; }
+bool hmc_tracking(const smcmc_hmc* h) { return hmc_adaptive(h) || h->track_cov; }
+
+// What an UpdateErrorMatrix that went through does to every chain (TSimpleHMC.H:833-847)
+__global__ void hmc_retune_kernel(double* lane_f64, int32_t* lane_i32, int npad, int nchains, double max_scale,
+                                  double min_scale, double orbit, int dim) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nchains) return;
+    double eps = lane_f64[(size_t)kHmcLaneMeanEpsilon * npad + c];
+    int L = lane_i32[(size_t)kHmcLaneLeapfrog * npad + c];
+    if (eps > 0) {                                                       // :835-839
+        eps = 0.2 * max_scale;
+        if (eps > 0.5 * min_scale) eps = 0.5 * min_scale;
+        if (eps < 0.05 * max_scale) eps = 0.05 * max_scale;
+    }
+    if (L > 0) {                                                         // :841-848
+        const double target = 0.4 * orbit;
+        L = (int)(target / __builtin_fabs(eps));
+        L = 2 * (L / 2 + 1);
+        if (L > 3 * dim) L = 3 * dim;
+        if (eps > 0) eps = target / L;
+    }
+    lane_f64[(size_t)kHmcLaneMeanEpsilon * npad + c] = eps;
+    lane_i32[(size_t)kHmcLaneLeapfrog * npad + c] = L;
+}
+
+template <typename T>
+__global__ void hmc_fill_lane_kernel(T* col, int nchains, T v) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < nchains) col[c] = v;
+}
+
 HmcParams hmc_params(smcmc_hmc* h, int nsteps, int init_only) {
     HmcParams p;
     std::memset(&p, 0, sizeof(p));
@@ -60,7 +128,62 @@ HmcParams hmc_params(smcmc_hmc* h, int nsteps, int init_only) {
     p.Eperm = h->d_E; p.like = h->d_like;
     p.q = h->d_q; p.pm = h->d_pm; p.qn = h->d_qn; p.pn = h->d_pn;
     p.lane_f64 = h->d_lane_f64; p.lane_i32 = h->d_lane_i32;
+    p.p0 = h->d_p0; p.qprev = h->d_qprev;
     return p;
+}
+
+template <typename T>
+int hmc_fill_lane(smcmc_hmc* h, T* col, T v) {
+    const int threads = 256;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(hmc_fill_lane_kernel<T>), dim3((h->nchains + threads - 1) / threads), dim3(threads), 0,
+                       h->stream, col, h->nchains, v);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hfail(h, SMCMC_ERR_HIP, std::string("lane fill launch: ") + hipGetErrorString(e));
+    return SMCMC_OK;
+}
+
+// buffers of the pooled tuning, allocated when it is first needed
+int hmc_tracking_buffers(smcmc_hmc* h) {
+    if (h->d_gacc) return SMCMC_OK;
+    const size_t vec = sizeof(double) * (size_t)h->npad * h->dim;
+    HMC_TRY(h, hipMalloc(&h->d_p0, vec));
+    HMC_TRY(h, hipMalloc(&h->d_qprev, vec));
+    HMC_TRY(h, hipMalloc(&h->d_gacc, sizeof(double) * hmc_gacc_doubles(h)));
+    HMC_TRY(h, hipMalloc(&h->d_moments, sizeof(double) * hmc_npacked(h)));
+    HMC_TRY(h, hipMalloc(&h->d_zero, sizeof(double) * h->dim));
+    HMC_TRY(h, hipMemsetAsync(h->d_p0, 0, vec, h->stream));
+    HMC_TRY(h, hipMemsetAsync(h->d_qprev, 0, vec, h->stream));
+    HMC_TRY(h, hipMemsetAsync(h->d_gacc, 0, sizeof(double) * hmc_gacc_doubles(h), h->stream));
+    HMC_TRY(h, hipMemsetAsync(h->d_moments, 0, sizeof(double) * hmc_npacked(h), h->stream));
+    HMC_TRY(h, hipMemsetAsync(h->d_zero, 0, sizeof(double) * h->dim, h->stream));
+    return SMCMC_OK;
+}
+
+// The pooled UpdateCovariance + UpdateErrorMatrix (TSimpleHMC.H:337-341) for the steps since the last one
+int hmc_sync(smcmc_hmc* h) {
+    const int steps = h->steps_in_window;
+    h->steps_in_window = 0;
+    if (steps == 0) return SMCMC_OK;
+    hipError_t e = launch_fold_reduce(h->d_gacc, h->dim, h->fold_nslices, h->d_moments, h->stream);
+    if (e != hipSuccess) return hfail(h, SMCMC_ERR_HIP, std::string("fold reduce launch: ") + hipGetErrorString(e));
+    HMC_TRY(h, hipMemsetAsync(h->d_gacc, 0, sizeof(double) * hmc_gacc_doubles(h), h->stream));
+    std::vector<double> M(hmc_npacked(h));
+    HMC_TRY(h, hipMemcpyAsync(M.data(), h->d_moments, M.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HMC_TRY(h, hipStreamSynchronize(h->stream));
+    if (!(M.back() > 0.0)) return SMCMC_OK;
+    HmcShared& S = *h->shared;
+    S.stepCount = (int)h->step_count;
+    S.leapfrogZero = (h->leapfrog == 0);
+    S.absorb(M.data(), steps);
+    if (S.updateErrorMatrix()) {
+        const int threads = 256;
+        hipLaunchKernelGGL(hmc_retune_kernel, dim3((h->nchains + threads - 1) / threads), dim3(threads), 0, h->stream,
+                           h->d_lane_f64, h->d_lane_i32, h->npad, h->nchains, S.maxScale, S.minScale, S.orbitLength,
+                           h->dim);
+        e = hipGetLastError();
+        if (e != hipSuccess) return hfail(h, SMCMC_ERR_HIP, std::string("retune launch: ") + hipGetErrorString(e));
+    }
+    return SMCMC_OK;
 }
 
 hipError_t hmc_dispatch(smcmc_hmc* h, const HmcParams& p) {
@@ -91,8 +214,11 @@ int smcmc_hmc_create(int dim, int nchains, int likelihood, uint64_t seed, uint32
     h->chain_offset = chain_offset; h->device = device;
     h->W = (dim <= 4 * kPanelCW) ? 4 : 8;
     h->npad = (nchains + kWave - 1) / kWave * kWave;
+    h->fold_nslices = fold_slices(dim);
+    h->slice_chains = ((h->npad / kWave + h->fold_nslices - 1) / h->fold_nslices) * kWave;
+    h->shared = new HmcShared(dim);
     *out = h;
-    HMC_TRY(h, hipSetDevice(device));
+    HMC_ON_DEVICE(h);
     const size_t vec = sizeof(double) * (size_t)h->npad * dim;
     HMC_TRY(h, hipMalloc(&h->d_q, vec));
     HMC_TRY(h, hipMalloc(&h->d_pm, vec));
@@ -116,12 +242,13 @@ int smcmc_hmc_create(int dim, int nchains, int likelihood, uint64_t seed, uint32
 
 int smcmc_hmc_destroy(smcmc_hmc* h) {
     if (!h) return SMCMC_OK;
-    if (h->d_q) {
-        (void)hipSetDevice(h->device);
-        (void)hipStreamSynchronize(h->stream);
-    }
+    HMC_ON_DEVICE(h);
+    if (h->d_q) (void)hipStreamSynchronize(h->stream);
     (void)hipFree(h->d_q); (void)hipFree(h->d_pm); (void)hipFree(h->d_qn); (void)hipFree(h->d_pn);
     (void)hipFree(h->d_E); (void)hipFree(h->d_like); (void)hipFree(h->d_lane_f64); (void)hipFree(h->d_lane_i32);
+    (void)hipFree(h->d_p0); (void)hipFree(h->d_qprev); (void)hipFree(h->d_gacc); (void)hipFree(h->d_moments);
+    (void)hipFree(h->d_zero);
+    delete h->shared;
     delete h;
     return SMCMC_OK;
 }
@@ -147,13 +274,75 @@ int smcmc_hmc_set_exact_arithmetic(smcmc_hmc* h, int exact) {
     return SMCMC_OK;
 }
 int smcmc_hmc_set_alpha(smcmc_hmc* h, double a) { if (!h) return SMCMC_ERR_INVALID; h->alpha = a; return SMCMC_OK; }
-int smcmc_hmc_set_mean_epsilon(smcmc_hmc* h, double e) { if (!h) return SMCMC_ERR_INVALID; h->mean_epsilon = e; return SMCMC_OK; }
-int smcmc_hmc_set_leapfrog(smcmc_hmc* h, int n) { if (!h) return SMCMC_ERR_INVALID; h->leapfrog = -n; return SMCMC_OK; }
-int smcmc_hmc_get_mean_epsilon(smcmc_hmc* h, double* e) { if (!h || !e) return SMCMC_ERR_INVALID; *e = h->mean_epsilon; return SMCMC_OK; }
+// SetMeanEpsilon / SetLeapFrog reach every chain's own copy (TSimpleHMC.H:181, 190)
+int smcmc_hmc_set_mean_epsilon(smcmc_hmc* h, double e) {
+    if (!h) return SMCMC_ERR_INVALID;
+    h->mean_epsilon = e;
+    if (!h->started) return SMCMC_OK;
+    HMC_ON_DEVICE(h);
+    return hmc_fill_lane<double>(h, h->d_lane_f64 + (size_t)kHmcLaneMeanEpsilon * h->npad, e);
+}
+int smcmc_hmc_set_leapfrog(smcmc_hmc* h, int n) {
+    if (!h) return SMCMC_ERR_INVALID;
+    h->leapfrog = -n;
+    if (!h->started) return SMCMC_OK;
+    HMC_ON_DEVICE(h);
+    return hmc_fill_lane<int32_t>(h, h->d_lane_i32 + (size_t)kHmcLaneLeapfrog * h->npad, (int32_t)-n);
+}
+// chain 0's fMeanEpsilon / fLeapFrogSteps (each chain retunes its own unless they are fixed)
+int smcmc_hmc_get_mean_epsilon(smcmc_hmc* h, double* e) {
+    if (!h || !e) return SMCMC_ERR_INVALID;
+    *e = h->mean_epsilon;
+    if (!h->started) return SMCMC_OK;
+    HMC_ON_DEVICE(h);
+    HMC_TRY(h, hipStreamSynchronize(h->stream));
+    HMC_TRY(h, hipMemcpy(e, h->d_lane_f64 + (size_t)kHmcLaneMeanEpsilon * h->npad, sizeof(double), hipMemcpyDeviceToHost));
+    return SMCMC_OK;
+}
+int smcmc_hmc_get_leapfrog(smcmc_hmc* h, int* steps) {
+    if (!h || !steps) return SMCMC_ERR_INVALID;
+    *steps = h->leapfrog;
+    if (!h->started) return SMCMC_OK;
+    HMC_ON_DEVICE(h);
+    int32_t v = 0;
+    HMC_TRY(h, hipStreamSynchronize(h->stream));
+    HMC_TRY(h, hipMemcpy(&v, h->d_lane_i32 + (size_t)kHmcLaneLeapfrog * h->npad, sizeof(int32_t), hipMemcpyDeviceToHost));
+    *steps = v;
+    return SMCMC_OK;
+}
+int smcmc_hmc_set_sync_interval(smcmc_hmc* h, int steps) {
+    if (!h || steps < 1) return SMCMC_ERR_INVALID;
+    h->sync_every = steps;
+    return SMCMC_OK;
+}
+int smcmc_hmc_set_track_covariance(smcmc_hmc* h, int on) {
+    if (!h) return SMCMC_ERR_INVALID;
+    h->track_cov = on != 0;
+    return SMCMC_OK;
+}
+int smcmc_hmc_moment_group(const smcmc_hmc* h) { return h ? h->slice_chains : 0; }
+int smcmc_hmc_get_tuning(smcmc_hmc* h, double* out) {
+    if (!h || !out) return SMCMC_ERR_INVALID;
+    const HmcShared& S = *h->shared;
+    out[0] = S.curTrace; out[1] = S.orbitLength; out[2] = S.updateCount; out[3] = S.covTrials;
+    out[4] = S.averageTrials; out[5] = S.stepsRemaining; out[6] = S.stepsSinceUpdate; out[7] = S.maxScale;
+    out[8] = S.minScale; out[9] = S.estTrace;
+    return SMCMC_OK;
+}
+int smcmc_hmc_get_average_point(smcmc_hmc* h, double* out) {
+    if (!h || !out) return SMCMC_ERR_INVALID;
+    std::copy(h->shared->average.begin(), h->shared->average.end(), out);
+    return SMCMC_OK;
+}
+int smcmc_hmc_get_covariance(smcmc_hmc* h, double* out) {
+    if (!h || !out) return SMCMC_ERR_INVALID;
+    std::copy(h->shared->cov.begin(), h->shared->cov.end(), out);
+    return SMCMC_OK;
+}
 
 int smcmc_hmc_start(smcmc_hmc* h, const double* x0, int broadcast) {
     if (!h || !x0) return SMCMC_ERR_INVALID;
-    HMC_TRY(h, hipSetDevice(h->device));
+    HMC_ON_DEVICE(h);
     const int D = h->dim, N = h->nchains, W = h->W;
     const size_t NP = (size_t)h->npad;
     if (h->likelihood == SMCMC_LIKE_QUADFORM) {
@@ -226,6 +415,17 @@ int smcmc_hmc_start(smcmc_hmc* h, const double* x0, int broadcast) {
     HMC_TRY(h, hipMemcpyAsync(h->d_lane_f64 + (size_t)SMCMC_LANE_ACCEPTANCE * NP, acc.data(), NP * sizeof(double),
                               hipMemcpyHostToDevice, h->stream));
     HMC_TRY(h, hipStreamSynchronize(h->stream));
+    // every chain's own fMeanEpsilon = 0.05 (:229), fLeapFrogSteps as the constructor / SetLeapFrog left it, fReversalLen = 0
+    int st = hmc_fill_lane<double>(h, h->d_lane_f64 + (size_t)kHmcLaneMeanEpsilon * NP, h->mean_epsilon);
+    if (st) return st;
+    st = hmc_fill_lane<int32_t>(h, h->d_lane_i32 + (size_t)kHmcLaneLeapfrog * NP, (int32_t)h->leapfrog);
+    if (st) return st;
+    // the running covariance starts from chain 0's point (:236-266)
+    std::vector<double> p0(D);
+    for (int d = 0; d < D; ++d) p0[d] = x[(size_t)d * NP];
+    h->shared->start(p0.data());
+    h->steps_in_window = 0;
+    if (h->d_gacc) HMC_TRY(h, hipMemsetAsync(h->d_gacc, 0, sizeof(double) * hmc_gacc_doubles(h), h->stream));
     h->started = true;
     return SMCMC_OK;
 }
@@ -234,19 +434,46 @@ int smcmc_hmc_step(smcmc_hmc* h, int nsteps) {
     if (!h) return SMCMC_ERR_INVALID;
     if (!h->started) return hfail(h, SMCMC_ERR_INVALID, "Must initialize starting point");   // :280-284
     if (nsteps <= 0) return SMCMC_OK;
-    if (h->mean_epsilon > 0.0 || h->leapfrog > 0)
-        return hfail(h, SMCMC_ERR_UNSUPPORTED,
-                     "the HIP path runs a fixed step: SetMeanEpsilon(negative) and SetLeapFrog(n) after Start "
-                     "(covariance-driven tuning of epsilon / leapfrog count is not on the device yet)");
-    HmcParams p = hmc_params(h, nsteps, 0);
-    hipError_t e = hmc_dispatch(h, p);
-    if (e != hipSuccess) return hfail(h, SMCMC_ERR_HIP, std::string("hmc step launch: ") + hipGetErrorString(e));
-    h->step_count += (uint32_t)nsteps;
+    HMC_ON_DEVICE(h);
+    if (!hmc_tracking(h)) {
+        // fixed step length and leapfrog count: the chains share nothing, one launch runs all the steps
+        HmcParams p = hmc_params(h, nsteps, 0);
+        hipError_t e = hmc_dispatch(h, p);
+        if (e != hipSuccess) return hfail(h, SMCMC_ERR_HIP, std::string("hmc step launch: ") + hipGetErrorString(e));
+        h->step_count += (uint32_t)nsteps;
+        return SMCMC_OK;
+    }
+    int st = hmc_tracking_buffers(h);
+    if (st) return st;
+    for (int s = 0; s < nsteps; ++s) {
+        HmcParams p = hmc_params(h, 1, 0);
+        p.adaptive = 1;
+        hipError_t e = hmc_dispatch(h, p);
+        if (e != hipSuccess) return hfail(h, SMCMC_ERR_HIP, std::string("hmc step launch: ") + hipGetErrorString(e));
+        h->step_count += 1u;
+        // UpdateCovariance (:338): the point each chain stood on, if its proposal's potential was finite (:336)
+        e = launch_fold(h->d_qprev, h->d_zero, h->nchains, h->npad, h->dim, h->slice_chains, h->fold_nslices, h->d_gacc,
+                        h->stream, h->d_lane_i32 + (size_t)kHmcLaneContributes * h->npad);
+        if (e != hipSuccess) return hfail(h, SMCMC_ERR_HIP, std::string("fold launch: ") + hipGetErrorString(e));
+        if (++h->steps_in_window >= h->sync_every) {
+            st = hmc_sync(h);
+            if (st) return st;
+        }
+    }
     return SMCMC_OK;
+}
+
+// the pooled update now, whatever the interval (a partial window at the end of a run)
+int smcmc_hmc_sync(smcmc_hmc* h) {
+    if (!h || !h->started) return SMCMC_ERR_INVALID;
+    HMC_ON_DEVICE(h);
+    if (!h->d_gacc) return SMCMC_OK;
+    return hmc_sync(h);
 }
 
 int smcmc_hmc_read_state(smcmc_hmc* h, double* q, double* momentum, double* logl) {
     if (!h) return SMCMC_ERR_INVALID;
+    HMC_ON_DEVICE(h);
     const int D = h->dim, N = h->nchains;
     const size_t NP = (size_t)h->npad;
     HMC_TRY(h, hipStreamSynchronize(h->stream));
@@ -261,6 +488,7 @@ int smcmc_hmc_read_state(smcmc_hmc* h, double* q, double* momentum, double* logl
 
 int smcmc_hmc_read_lane_f64(smcmc_hmc* h, int field, double* out) {
     if (!h || !out || field < 0 || field >= SMCMC_LANE_F64_COUNT_) return SMCMC_ERR_INVALID;
+    HMC_ON_DEVICE(h);
     HMC_TRY(h, hipStreamSynchronize(h->stream));
     HMC_TRY(h, hipMemcpy(out, h->d_lane_f64 + (size_t)field * h->npad, (size_t)h->nchains * sizeof(double),
                          hipMemcpyDeviceToHost));
@@ -269,6 +497,7 @@ int smcmc_hmc_read_lane_f64(smcmc_hmc* h, int field, double* out) {
 
 int smcmc_hmc_read_lane_i32(smcmc_hmc* h, int field, int32_t* out) {
     if (!h || !out || field < 0 || field >= SMCMC_LANE_I32_COUNT_) return SMCMC_ERR_INVALID;
+    HMC_ON_DEVICE(h);
     HMC_TRY(h, hipStreamSynchronize(h->stream));
     HMC_TRY(h, hipMemcpy(out, h->d_lane_i32 + (size_t)field * h->npad, (size_t)h->nchains * sizeof(int32_t),
                          hipMemcpyDeviceToHost));

@@ -27,8 +27,54 @@
 
 namespace smcmc {
 
+// per-chain columns of the HMC engine that reuse slots of smcmc_lane_f64 / smcmc_lane_i32 (include/smcmc.h)
+constexpr int kHmcLaneMeanEpsilon = SMCMC_LANE_SIGMA;         // fMeanEpsilon
+constexpr int kHmcLaneReversalLen = SMCMC_LANE_RIGIDITY;      // fReversalLen
+constexpr int kHmcLaneLeapfrog = SMCMC_LANE_NEXT_UPDATE;      // fLeapFrogSteps (signed as the reference keeps it)
+constexpr int kHmcLaneContributes = SMCMC_LANE_SUCCESSES;     // okLeap && isfinite(fProposedPotential) of the latest step
+
+// max over the 64 lanes of a wavefront
+__device__ __forceinline__ int wave_max_i32(int v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const int o = __shfl_xor(v, off, 64);
+        v = (o > v) ? o : v;
+    }
+    return v;
+}
+
+// TSimpleHMC.H:302-323: what a step does to the chain's own step length, leapfrog count and reversal length
+__device__ __forceinline__ void hmc_retune_after_leapfrog(int status, double eps, double& mean_eps, int& lfrog,
+                                                          double& reversal) {
+    if (lfrog > 0) {
+        if (status != 2) {
+            if (mean_eps > 0 && reversal > mean_eps) {
+                const double target = reversal / 8.0;
+                const double delta = target - mean_eps;
+                if (delta > 0.0) mean_eps += 0.1 * delta;
+            }
+            if (lfrog < 50) lfrog += 1;
+        } else {
+            if (reversal < mean_eps) {
+                reversal = __builtin_fabs(lfrog * eps);
+            } else {
+                reversal = 0.95 * reversal;
+                reversal += 0.05 * __builtin_fabs(lfrog * eps);
+            }
+            if (lfrog > 3) lfrog -= 1;
+            if (mean_eps > 0) mean_eps *= 0.99;
+        }
+    }
+}
+
 struct HmcParams {
     int nchains, npad, dim, nsteps, leapfrog, init_only;
+    int adaptive;          // 1: step length and leapfrog count are per chain (lanes) and retuned every step
+                           // (TSimpleHMC.H:302-323, 342-344); one step per launch, the pre-step point kept in qprev
+    int gradient_type;     // PotentialGradient's type (TSimpleHMC.H:467-532): 0 the likelihood's gradient, 2 the
+                           // covariant approximation (cov_error, cov_average), 5 zero
+    double* p0;            // adaptive: the momentum LeapFrog started from (the reversal test, :633-638) [dim][npad]
+    double* qprev;         // adaptive: fAccepted as UpdateCovariance sees it (:338)                     [dim][npad]
     uint32_t step0, chain_offset;
     uint64_t seed;
     double alpha, abs_eps;
@@ -239,6 +285,12 @@ __global__ void __launch_bounds__(W * kWave) hmc_step_kernel(const HmcParams p) 
         return;
     }
 
+    // adaptive mode: the chain's own step length, leapfrog count and reversal length (lanes), one step per launch
+    double mean_eps = p.adaptive ? lf[kHmcLaneMeanEpsilon * NP] : -p.abs_eps;
+    int lfrog = p.adaptive ? li[kHmcLaneLeapfrog * NP] : -p.leapfrog;
+    double reversal = p.adaptive ? lf[kHmcLaneReversalLen * NP] : 0.0;
+    int contributes = 1;
+
     for (int s = 0; s < p.nsteps; ++s) {
         const uint64_t step = (uint64_t)(p.step0 + (uint32_t)s + 1u);   // ++fStepCount, :286
         ++trials;
@@ -263,6 +315,7 @@ __global__ void __launch_bounds__(W * kWave) hmc_step_kernel(const HmcParams p) 
                     v = p.alpha * m + mix * r;
                 }
                 p.pn[(size_t)i * NP + chain] = v;
+                if (p.adaptive) p.p0[(size_t)i * NP + chain] = v;               // LeapFrog: momentum = pNew (:587)
                 p.qn[(size_t)i * NP + chain] = p.q[(size_t)i * NP + chain];   // LeapFrog: qNew = position (:586)
             }
         }
@@ -277,14 +330,18 @@ __global__ void __launch_bounds__(W * kWave) hmc_step_kernel(const HmcParams p) 
 
         // ---- epsilon (:297-298) ----
         const smcmc_u32x4 eblk = smcmc_draw_block(p.seed, gid, step, ew >> 2, SMCMC_STREAM_HMC);
-        const double lo = 0.9 * p.abs_eps, hi = 1.1 * p.abs_eps;
+        const double abs_eps = __builtin_fabs(mean_eps);
+        const double lo = 0.9 * abs_eps, hi = 1.1 * abs_eps;
         const double eps = lo + (hi - lo) * smcmc_u01(smcmc_select_word(eblk, ew & 3u));
         const smcmc_u32x4 ablk = smcmc_draw_block(p.seed, gid, step, (ew + 1u) >> 2, SMCMC_STREAM_HMC);
         const double uacc = smcmc_u01(smcmc_select_word(ablk, (ew + 1u) & 3u));
 
-        // ---- LeapFrog (:582-651) ----
-        const int L = p.leapfrog;
-        if (L < 1) {
+        // ---- LeapFrog (:582-651).  Chains of the group may differ in their leapfrog count: the group runs to
+        // the largest one, a chain takes its last (half) kick at its own count and then stands still. ----
+        const int L = active ? (lfrog < 0 ? -lfrog : lfrog) : 0;
+        const int Lmax = wave_max_i32(L);
+        int status = 1;                                                        // leapStatus
+        if (Lmax < 1) {
             // the one-step shortcut (:598-611): qNew += eps*(momentum + pNew)/2 with pNew == momentum
 #pragma unroll
             for (int il = 0; il < CW; ++il) {
@@ -300,16 +357,19 @@ __global__ void __launch_bounds__(W * kWave) hmc_step_kernel(const HmcParams p) 
 #pragma unroll
             for (int il = 0; il < CW; ++il) {                                  // :618-620
                 const int i = il * W + w;
-                if (i < D) {
+                if (i < D && L >= 1) {
                     const double m = p.pn[(size_t)i * NP + chain];
                     p.pn[(size_t)i * NP + chain] = m - eps * gr[il] / 2.0;
                 }
             }
-            for (int ls = 0; ls < L - 1; ++ls) {                               // :623-639
+            for (int ls = 0; ls < Lmax; ++ls) {
+                // iteration ls of a chain with L steps: ls < L - 1 the body of :623-639, ls == L - 1 the last
+                // position step and half kick of :641-648, afterwards nothing
+                const bool live = ls < L, last = ls == L - 1;
 #pragma unroll
                 for (int il = 0; il < CW; ++il) {
                     const int i = il * W + w;
-                    if (i < D) {
+                    if (i < D && live) {
                         const double m = p.pn[(size_t)i * NP + chain];
                         const double qv = p.qn[(size_t)i * NP + chain];
                         p.qn[(size_t)i * NP + chain] = qv + eps * m;
@@ -319,38 +379,31 @@ __global__ void __launch_bounds__(W * kWave) hmc_step_kernel(const HmcParams p) 
 #pragma unroll
                 for (int il = 0; il < CW; ++il) {
                     const int i = il * W + w;
-                    if (i < D) {
+                    if (i < D && live) {
                         const double m = p.pn[(size_t)i * NP + chain];
-                        p.pn[(size_t)i * NP + chain] = m - eps * gr[il];
+                        p.pn[(size_t)i * NP + chain] = last ? m - eps * gr[il] / 2.0 : m - eps * gr[il];
                     }
                 }
-                // the reversal test (:633-638) only feeds the leapfrog auto-tuning, which
-                // SetLeapFrog switches off
-            }
-#pragma unroll
-            for (int il = 0; il < CW; ++il) {                                  // :641-643
-                const int i = il * W + w;
-                if (i < D) {
-                    const double m = p.pn[(size_t)i * NP + chain];
-                    const double qv = p.qn[(size_t)i * NP + chain];
-                    p.qn[(size_t)i * NP + chain] = qv + eps * m;
-                }
-            }
-            gradient();                                                        // :645
-#pragma unroll
-            for (int il = 0; il < CW; ++il) {                                  // :646-648
-                const int i = il * W + w;
-                if (i < D) {
-                    const double m = p.pn[(size_t)i * NP + chain];
-                    p.pn[(size_t)i * NP + chain] = m - eps * gr[il] / 2.0;
+                if (p.adaptive && ls < Lmax - 1) {
+                    // has the direction reversed (:633-638)?  Only the automatic leapfrog count listens.
+                    __syncthreads();
+                    double inner = 0.0;
+                    gather([&](int il, double& a, double& b) {
+                               const int i = il * W + w;
+                               a = (i < D) ? p.pn[(size_t)i * NP + chain] : 0.0;
+                               b = (i < D) ? p.p0[(size_t)i * NP + chain] : 0.0;
+                           },
+                           [&](int, double a, double b) { inner += a * b; });
+                    if (ls < L - 1 && !(inner >= 0.0)) status = 2;
                 }
             }
         }
         __syncthreads();
+        if (p.adaptive) hmc_retune_after_leapfrog(status, eps, mean_eps, lfrog, reversal);   // :302-323 (wavefront 0 holds the status)
 
         // ---- proposed kinetic energy and potential (:326-327), dimension order ----
         double ke1 = 0.0;
-        const double lsum = log_likelihood_at_qn(L >= 1, ke1);
+        const double lsum = log_likelihood_at_qn(Lmax >= 1, ke1);
 
         // ---- Hamiltonian test (:333-387), wavefront 0 decides ----
         if (w == 0) {
@@ -366,6 +419,9 @@ __global__ void __launch_bounds__(W * kWave) hmc_step_kernel(const HmcParams p) 
         __syncthreads();
         const bool take = verdict_i[lane] != 0;
         pot_prop = verdict_f[lane];
+        // UpdateCovariance runs on a finite proposal (okLeap is never zero); otherwise the step length shrinks (:336-344)
+        contributes = __builtin_isfinite(pot_prop) ? 1 : 0;
+        if (p.adaptive && !contributes && mean_eps > 0) mean_eps = 0.3 * mean_eps;
         if (take) {
             pot_acc = pot_prop;
             acceptance = (acceptance * 4999.0 + 1.0) / 5000.0;                  // :386
@@ -378,6 +434,7 @@ __global__ void __launch_bounds__(W * kWave) hmc_step_kernel(const HmcParams p) 
         for (int il = 0; il < CW; ++il) {
             const int i = il * W + w;
             if (i < D && active) {
+                if (p.adaptive) p.qprev[(size_t)i * NP + chain] = p.q[(size_t)i * NP + chain];   // what :338 folds
                 if (take) {                                                     // :380-383
                     p.q[(size_t)i * NP + chain] = p.qn[(size_t)i * NP + chain];
                     p.pm[(size_t)i * NP + chain] = p.pn[(size_t)i * NP + chain];
@@ -396,6 +453,12 @@ __global__ void __launch_bounds__(W * kWave) hmc_step_kernel(const HmcParams p) 
         li[SMCMC_LANE_NACCEPT * NP] = naccept;
         li[SMCMC_LANE_LAST_ACCEPT * NP] = last_accept;
         li[SMCMC_LANE_TRIALS * NP] = trials;
+        if (p.adaptive) {
+            lf[kHmcLaneMeanEpsilon * NP] = mean_eps;
+            lf[kHmcLaneReversalLen * NP] = reversal;
+            li[kHmcLaneLeapfrog * NP] = lfrog;
+            li[kHmcLaneContributes * NP] = contributes;
+        }
     }
 }
 

@@ -52,7 +52,10 @@ inline size_t hmc_exact_ex_doubles(int dim) { return (size_t)((dim + 15) / 16) *
 template <int kMfTI, bool FUSED = true>
 __global__ void __launch_bounds__(kMfW* kWave, 1) hmc_mfma_kernel(const HmcParams p) {
     __shared__ double qs[16 * kMfW * kMfTI * kMfCT];   // [component][chain]: the published vector
-    __shared__ int verdict[kMfCT];
+    // one 16-component tile per wavefront x 32 chains: ordered sums that must leave qs (the positions) alone; its
+    // first bytes double as the verdict of the Hamiltonian test (with kMfTI = 4 the two arrays fill the 160 KB)
+    __shared__ double rs[16 * kMfW * kMfCT];
+    int* const verdict = (int*)rs;
 
     const int lane = threadIdx.x & (kWave - 1);
     const int w = threadIdx.x / kWave;
@@ -96,6 +99,26 @@ __global__ void __launch_bounds__(kMfW* kWave, 1) hmc_mfma_kernel(const HmcParam
         if (summer)
             for (int i = 0; i < D; ++i) s += qs[i * kMfCT + lane];
         return s;
+    };
+
+    // sum over the components, ascending, of value(t, ct, r) for every chain, 128 components at a time through rs
+    auto ordered_sum_tiles = [&](auto&& value) {
+        double sacc = 0.0;
+#pragma unroll
+        for (int t = 0; t < kMfTI; ++t) {
+            __syncthreads();
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    rs[(w * 16 + 4 * r + rq) * kMfCT + 16 * ct + c] = (owns(t) && comp(t, r) < D) ? value(t, ct, r) : 0.0;
+            __syncthreads();
+            if (summer)
+                for (int k = 0; k < 16 * kMfW; ++k)
+                    if (16 * kMfW * t + k < D) sacc += rs[k * kMfCT + lane];
+        }
+        __syncthreads();
+        return sacc;
     };
 
     // gr = Error q for the owned components, q = the positions in qs (PotentialGradient,
@@ -204,6 +227,16 @@ __global__ void __launch_bounds__(kMfW* kWave, 1) hmc_mfma_kernel(const HmcParam
         return;
     }
 
+    // adaptive mode: the chains' own step length and leapfrog count (lanes); the summing lanes carry their chain's
+    // tuning state through the step (one step per launch)
+    double mean_eps = 0.0, reversal = 0.0;
+    int lfrog = 0, contributes = 1;
+    if (summer && p.adaptive) {
+        mean_eps = p.lane_f64[kHmcLaneMeanEpsilon * NP + mychain];
+        reversal = p.lane_f64[kHmcLaneReversalLen * NP + mychain];
+        lfrog = p.lane_i32[kHmcLaneLeapfrog * NP + mychain];
+    }
+
     for (int s = 0; s < p.nsteps; ++s) {
         const uint64_t step = (uint64_t)(p.step0 + (uint32_t)s + 1u);   // ++fStepCount, :286
         ++trials;
@@ -212,9 +245,17 @@ __global__ void __launch_bounds__(kMfW* kWave, 1) hmc_mfma_kernel(const HmcParam
         // ---- ProposeMomentum (:554-570) ----
         const double mix = __builtin_sqrt(1.0 - p.alpha * p.alpha);
         double eps[2];
+        int Lc[2];   // leapfrog count of this lane's two chains
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
             const uint32_t gid = p.chain_offset + (uint32_t)(base + 16 * ct + c);
+            double abs_eps = p.abs_eps;
+            Lc[ct] = p.leapfrog;
+            if (p.adaptive) {
+                abs_eps = __builtin_fabs(p.lane_f64[kHmcLaneMeanEpsilon * NP + base + 16 * ct + c]);
+                const int l = p.lane_i32[kHmcLaneLeapfrog * NP + base + 16 * ct + c];
+                Lc[ct] = (base + 16 * ct + c < p.nchains) ? (l < 0 ? -l : l) : 0;
+            }
 #pragma unroll
             for (int t = 0; t < kMfTI; ++t)
 #pragma unroll
@@ -235,42 +276,54 @@ __global__ void __launch_bounds__(kMfW* kWave, 1) hmc_mfma_kernel(const HmcParam
                         }
                     }
                     pn[t][ct][r] = v;
+                    if (p.adaptive && owns(t) && i < D) p.pn[(size_t)i * NP + base + 16 * ct + c] = v;   // LeapFrog: momentum = pNew (:587)
                     __builtin_amdgcn_sched_barrier(0);   // one draw at a time: interleaved they exhaust the registers
                 }
             // ---- epsilon (:297-298) ----
             const smcmc_u32x4 eblk = smcmc_draw_block(p.seed, gid, step, ew >> 2, SMCMC_STREAM_HMC);
-            const double lo = 0.9 * p.abs_eps, hi = 1.1 * p.abs_eps;
+            const double lo = 0.9 * abs_eps, hi = 1.1 * abs_eps;
             eps[ct] = lo + (hi - lo) * smcmc_u01(smcmc_select_word(eblk, ew & 3u));
         }
         const double ke0 = kinetic();                                   // :292
         load_q();
 
-        // ---- LeapFrog (:582-651) ----
-        const int L = p.leapfrog;
-        auto kick = [&](bool half) {                                    // pNew[i] -= eps*grad[i] (/2.0)
+        // ---- LeapFrog (:582-651).  Chains of the workgroup may differ in their leapfrog count: the workgroup runs to
+        // the largest one, a chain takes its last (half) kick at its own count and then stands still. ----
+        const int Lmax = wave_max_i32(Lc[0] > Lc[1] ? Lc[0] : Lc[1]);
+        const int Lmine = lfrog < 0 ? -lfrog : lfrog;                   // summing lanes: their chain's count
+        int status = 1;                                                 // leapStatus of the summing lane's chain
+        // iteration ls of a chain with L steps: ls < L - 1 the body of :623-639, ls == L - 1 the last position step
+        // and half kick of :641-648, afterwards nothing; ls = -1 is the first half kick of :618-620
+        auto kick = [&](int ls) {
+            const bool live0 = ls < Lc[0], live1 = ls < Lc[1];
+            const bool half0 = (ls < 0) || (ls == Lc[0] - 1), half1 = (ls < 0) || (ls == Lc[1] - 1);
 #pragma unroll
             for (int t = 0; t < kMfTI; ++t)
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
+                        const bool live = ct ? live1 : live0, half = ct ? half1 : half0;
                         const double m = pn[t][ct][r];
-                        pn[t][ct][r] = half ? m - eps[ct] * gr[t][ct][r] / 2.0 : m - eps[ct] * gr[t][ct][r];
+                        const double k = half ? m - eps[ct] * gr[t][ct][r] / 2.0 : m - eps[ct] * gr[t][ct][r];
+                        pn[t][ct][r] = live ? k : m;
                     }
         };
-        auto drift = [&]() {                                            // qNew[i] += eps*pNew[i]
+        auto drift = [&](int ls) {                                      // qNew[i] += eps*pNew[i]
 #pragma unroll
             for (int t = 0; t < kMfTI; ++t) {
                 if (!owns(t)) continue;
 #pragma unroll
-                for (int ct = 0; ct < 2; ++ct)
+                for (int ct = 0; ct < 2; ++ct) {
+                    if (!(ls < Lc[ct])) continue;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         if (comp(t, r) < D) qs[slot(t, ct, r)] = qs[slot(t, ct, r)] + eps[ct] * pn[t][ct][r];
                     }
+                }
             }
         };
-        if (L < 1) {
+        if (Lmax < 1) {
             // the one-step shortcut (:598-611): qNew += eps*(momentum + pNew)/2 with pNew == momentum
 #pragma unroll
             for (int t = 0; t < kMfTI; ++t) {
@@ -286,15 +339,24 @@ __global__ void __launch_bounds__(kMfW* kWave, 1) hmc_mfma_kernel(const HmcParam
             gradient();                                                 // for the potential below
         } else {
             gradient();                                                 // :615
-            kick(true);                                                 // :618-620
-            for (int ls = 0; ls < L - 1; ++ls) {                        // :623-639
-                drift();
+            kick(-1);                                                   // :618-620
+            for (int ls = 0; ls < Lmax; ++ls) {
+                drift(ls);
                 gradient();
-                kick(false);
+                kick(ls);
+                if (p.adaptive && ls < Lmax - 1) {
+                    // has the direction reversed (:633-638)?  inner += pNew[j]*momentum[j], dimension order; the
+                    // starting momentum was parked in p.pn
+                    const double inner = ordered_sum_tiles([&](int t, int ct, int r) {
+                        return pn[t][ct][r] * p.pn[(size_t)comp(t, r) * NP + base + 16 * ct + c];
+                    });
+                    if (summer && ls < Lmine - 1 && !(inner >= 0.0)) status = 2;
+                }
             }
-            drift();                                                    // :641-643
-            gradient();                                                 // :645
-            kick(true);                                                 // :646-648
+        }
+        if (summer && p.adaptive) {
+            const double my_eps = (lane < 16) ? eps[0] : eps[1];        // chain base + lane is this lane's chain tile lane >> 4
+            hmc_retune_after_leapfrog(status, my_eps, mean_eps, lfrog, reversal);   // :302-323
         }
 
         // ---- proposed potential and kinetic energy (:326-327), dimension order ----
@@ -310,6 +372,9 @@ __global__ void __launch_bounds__(kMfW* kWave, 1) hmc_mfma_kernel(const HmcParam
             const double delta = (pot_prop + ke1) - (pot_acc + ke0);
             const double trial = -smcmc_log_pos(uacc);
             const bool reject = (delta > trial) || !__builtin_isfinite(delta) || !(mychain < p.nchains);
+            // UpdateCovariance runs on a finite proposal (okLeap is never zero); otherwise the step length shrinks (:336-344)
+            contributes = __builtin_isfinite(pot_prop) ? 1 : 0;
+            if (p.adaptive && !contributes && mean_eps > 0) mean_eps = 0.3 * mean_eps;
             verdict[lane] = reject ? 0 : 1;
             if (!reject) {
                 pot_acc = pot_prop;
@@ -331,6 +396,7 @@ __global__ void __launch_bounds__(kMfW* kWave, 1) hmc_mfma_kernel(const HmcParam
                 for (int r = 0; r < 4; ++r) {
                     const int i = comp(t, r);
                     if (owns(t) && i < D && chain < p.nchains) {
+                        if (p.adaptive) p.qprev[(size_t)i * NP + chain] = p.q[(size_t)i * NP + chain];   // what :338 folds
                         if (take) {                                     // :380-383
                             p.q[(size_t)i * NP + chain] = p.qn[(size_t)i * NP + chain];
                             p.pm[(size_t)i * NP + chain] = pn[t][ct][r];
@@ -350,6 +416,12 @@ __global__ void __launch_bounds__(kMfW* kWave, 1) hmc_mfma_kernel(const HmcParam
         p.lane_i32[SMCMC_LANE_NACCEPT * NP + mychain] = naccept;
         p.lane_i32[SMCMC_LANE_LAST_ACCEPT * NP + mychain] = last_accept;
         p.lane_i32[SMCMC_LANE_TRIALS * NP + mychain] = trials;
+        if (p.adaptive) {
+            p.lane_f64[kHmcLaneMeanEpsilon * NP + mychain] = mean_eps;
+            p.lane_f64[kHmcLaneReversalLen * NP + mychain] = reversal;
+            p.lane_i32[kHmcLaneLeapfrog * NP + mychain] = lfrog;
+            p.lane_i32[kHmcLaneContributes * NP + mychain] = contributes;
+        }
     }
 }
 

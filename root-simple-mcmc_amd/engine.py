@@ -422,8 +422,10 @@ def selftest_mfma_strip(a, b, device=0):
 
 
 class HmcEngine:
-    """N independent sMCMC::TSimpleHMC chains (reference TSimpleHMC.H:119-973) with the
-    analytic gradient of a device likelihood, fixed |epsilon| and leapfrog count."""
+    """N sMCMC::TSimpleHMC chains (reference TSimpleHMC.H:119-973) with the analytic gradient of a device
+    likelihood.  SetMeanEpsilon(negative) + SetLeapFrog(n) fix the step: independent chains, many steps per launch.
+    Otherwise every chain retunes its own step length and leapfrog count (:302-345) and the covariance-driven
+    retuning (:665-858) is pooled over the ensemble every SetSyncInterval steps."""
 
     def __init__(self, dim, nchains=1, likelihood=LIKE_ISO_GAUSS, likelihood_params=None, seed=20240607,
                  chain_offset=0, device=0, stream=None, exact=True):
@@ -471,6 +473,38 @@ class HmcEngine:
         self._check(self._lib.smcmc_hmc_get_mean_epsilon(self._h, C.byref(out)))
         return out.value
 
+    def GetLeapFrog(self):
+        """fLeapFrogSteps of chain 0, signed as the reference keeps it (negative = fixed by SetLeapFrog)."""
+        out = C.c_int(0)
+        self._check(self._lib.smcmc_hmc_get_leapfrog(self._h, C.byref(out)))
+        return out.value
+
+    def SetSyncInterval(self, steps): self._check(self._lib.smcmc_hmc_set_sync_interval(self._h, int(steps)))
+    def TrackCovariance(self, on=True): self._check(self._lib.smcmc_hmc_set_track_covariance(self._h, int(on)))
+    def sync(self): self._check(self._lib.smcmc_hmc_sync(self._h))
+
+    @property
+    def moment_group(self):
+        return self._lib.smcmc_hmc_moment_group(self._h)
+
+    @property
+    def tuning(self):
+        out = np.zeros(len(_capi.HMC_TUNING))
+        self._check(self._lib.smcmc_hmc_get_tuning(self._h, _ptr(out)))
+        return dict(zip(_capi.HMC_TUNING, out))
+
+    @property
+    def average(self):
+        out = np.zeros(self.dim)
+        self._check(self._lib.smcmc_hmc_get_average_point(self._h, _ptr(out)))
+        return out
+
+    @property
+    def covariance(self):
+        out = np.zeros((self.dim, self.dim))
+        self._check(self._lib.smcmc_hmc_get_covariance(self._h, _ptr(out)))
+        return out
+
     def Start(self, start):
         start = _f64(start)
         broadcast = int(start.ndim == 1)
@@ -489,11 +523,11 @@ class HmcEngine:
         return q, m, logl
 
     def lane(self, name):
-        if name in _capi.LANE_F64:
+        if name in _capi.HMC_LANE_F64:
             out = np.zeros(self.nchains)
-            self._check(self._lib.smcmc_hmc_read_lane_f64(self._h, _capi.LANE_F64[name], _ptr(out)))
+            self._check(self._lib.smcmc_hmc_read_lane_f64(self._h, _capi.HMC_LANE_F64[name], _ptr(out)))
             return out
         out = np.zeros(self.nchains, np.int32)
-        self._check(self._lib.smcmc_hmc_read_lane_i32(self._h, _capi.LANE_I32[name],
+        self._check(self._lib.smcmc_hmc_read_lane_i32(self._h, _capi.HMC_LANE_I32[name],
                                                       out.ctypes.data_as(C.POINTER(C.c_int32))))
         return out

@@ -79,9 +79,9 @@ def test_example_continues_a_chain_from_its_output(gpu, tmp_path):
     assert abs(float(b["AdaptiveCovarianceTrace"]) / 5.0 - 1.0) < 0.25
 
 
-def _build_hmc(tmp_path):
+def _build_hmc(tmp_path, *defines):
     exe = str(tmp_path / "hmc_amd.exe")
-    cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-Werror", f"-I{os.path.join(ROOT, 'include')}",
+    cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-Werror", f"-I{os.path.join(ROOT, 'include')}", *defines,
            os.path.join(ROOT, "examples", "SimpleHMC_amd.C"), f"-L{LIBDIR}", "-lsmcmc_amd",
            f"-Wl,-rpath,{LIBDIR}", "-Wl,-rpath,/opt/rocm/lib", "-o", exe]
     r = subprocess.run(cmd, capture_output=True, text=True)
@@ -101,7 +101,7 @@ def test_hmc_example_runs(gpu, tmp_path, fused):
     exe = _build_hmc(tmp_path)
     out = tmp_path / "hmc.csv"
     dim, trials = 20, 400
-    r = subprocess.run([exe, str(trials), str(out), str(dim), "96", str(fused)], capture_output=True, text=True,
+    r = subprocess.run([exe, str(trials), str(out), str(dim), "96", str(fused), "0"], capture_output=True, text=True,
                        timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     lines = open(out).read().splitlines()
@@ -213,3 +213,39 @@ def test_step_column_matches_the_reference_chain(gpu, oracle, tmp_path, metropol
         assert float(row[col["LogLikelihood"]]) == logl and int(row[col["TotalSteps"]]) == total
     rejected = [w for w in want[1:] if np.any(w[0] != 0) and w[3] > 0]
     assert len(rejected) > 0
+
+
+@pytest.mark.gpu
+def test_hmc_example_with_the_reference_defaults(gpu, oracle, tmp_path):
+    """SimpleHMC.C:46-72 as it stands -- no SetMeanEpsilon, no SetLeapFrog -- with THardLogLikelihood (its
+    USE_HARD_LIKELIHOOD switch) and one chain: the tree's MeanEpsilon / Leapfrog / Trace / Orbit / Accepted columns are
+    those of the CPU restatement of TSimpleHMC, step for step."""
+    exe = _build_hmc(tmp_path, "-DUSE_HARD_LIKELIHOOD")
+    out = tmp_path / "hmc_default.csv"
+    dim, trials = 6, 150
+    r = subprocess.run([exe, str(trials), str(out), str(dim), "1", "0", "1"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = open(out).read().splitlines()
+    header = lines[0].split(",")
+    col = {h: i for i, h in enumerate(header) if h}
+    rows = [l.split(",") for l in lines[1:]]
+    assert len(rows) == trials + 1
+
+    h = oracle.Hmc(dim, kind=2, params=[100.0], potential_from_gradient=True)
+    h.start(np.ones(dim))
+    h.run(100 + dim)
+    grads = h.scalars["gradient_count"]
+    for k in range(trials):
+        h.step()
+        sc = h.scalars
+        row = rows[k + 1]
+        assert float(row[col["MeanEpsilon"]]) == sc["mean_epsilon"], k
+        assert int(row[col["Leapfrog"]]) == int(sc["leapfrog_steps"]), k
+        assert float(row[col["LogLikelihood"]]) == sc["accepted_potential"], k
+        assert float(row[col["Trace"]]) == sc["trace"] and float(row[col["Orbit"]]) == sc["orbit"], k
+        assert np.array_equal([float(row[col[f"Accepted[{d}]"]]) for d in range(dim)], h.accepted)
+        assert int(row[col["Steps"]]) == 100 + dim + k + 1
+    assert f"{int(h.scalars['gradient_count'])} gradients" in r.stdout and h.scalars["gradient_count"] > grads
+    assert h.scalars["updates"] >= 2                                  # UpdateErrorMatrix went through on the way
+    leap = [int(r_[col["Leapfrog"]]) for r_ in rows[1:]]
+    assert len(set(leap)) > 1                                         # the leapfrog count moved

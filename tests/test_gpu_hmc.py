@@ -102,12 +102,13 @@ def test_hmc_quadform_potential_close_to_reference_order(gpu, oracle):
     assert abs(h1.scalars["accepted_potential"] - h2.scalars["accepted_potential"]) < 1e-11 * abs(h1.scalars["accepted_potential"])
 
 
-def test_hmc_needs_fixed_step(gpu):
+def test_hmc_default_configuration_runs(gpu):
+    """After Start the step length is 0.05 > 0 and the leapfrog count 10 > 0 (TSimpleHMC.H:133, 229): the chains
+    retune themselves (nothing is refused; the first rounds of this engine answered SMCMC_ERR_UNSUPPORTED here)."""
     e = gpu.HmcEngine(5, 10)
     e.Start(np.zeros(5))
-    with pytest.raises(gpu.SmcmcError) as err:
-        e.Step(1)                    # fMeanEpsilon = 0.05 > 0 after Start: covariance-driven tuning is not on the device
-    assert err.value.status == 5
+    e.Step(3)
+    assert np.all(e.lane("trials") == 3) and np.all(e.lane("leapfrog") > 0)
 
 
 def test_hmc_posterior_iso(gpu):
@@ -119,3 +120,101 @@ def test_hmc_posterior_iso(gpu):
     assert np.max(np.abs(q.mean(axis=1))) < 0.08
     assert np.max(np.abs(np.cov(q) - np.eye(dim))) < 0.12
     assert e.lane("naccept").mean() / 300 > 0.8
+
+
+# ---------------------------------------------------------------- the chains retune themselves (TSimpleHMC.H:302-345, 665-858)
+def _adaptive_pair(gpu, oracle, dim, nchains, kind, params, exact, sync, fix_leapfrog=None, fix_epsilon=None):
+    e = gpu.HmcEngine(dim, nchains, likelihood=kind, likelihood_params=params, seed=5, exact=exact)
+    e.SetSyncInterval(sync)
+    o = oracle.HmcEnsemble(nchains, dim, kind=kind, params=params, seed=5, group=e.moment_group, sync_every=sync,
+                           potential_from_gradient=True, fused_gradient=not exact)
+    return e, o
+
+
+def _same_hmc(e, o, tag):
+    q, m, logl = e.state()
+    oq, om = o.state()
+    assert np.array_equal(q, oq), f"{tag}: positions"
+    assert np.array_equal(m, om), f"{tag}: momenta"
+    assert np.array_equal(logl, -o.lane("accepted_potential")), f"{tag}: potentials"
+    assert np.array_equal(e.lane("mean_epsilon"), o.lane("mean_epsilon")), f"{tag}: fMeanEpsilon"
+    assert np.array_equal(e.lane("leapfrog"), o.lane("leapfrog_steps").astype(np.int32)), f"{tag}: fLeapFrogSteps"
+    assert np.array_equal(e.lane("reversal_len"), o.lane("reversal_len")), f"{tag}: fReversalLen"
+    assert np.array_equal(e.lane("acceptance"), o.lane("current_acceptance")), f"{tag}: fCurrentAcceptance"
+    t, s = e.tuning, o.shared
+    for name in ("trace", "orbit", "updates", "cov_trials", "average_trials", "steps_remaining", "steps_since_update",
+                 "est_trace"):
+        assert t[name] == s[name], f"{tag}: shared {name}: {t[name]} != {s[name]}"
+    assert np.array_equal(e.average, o.average), f"{tag}: fAveragePoint"
+    assert np.array_equal(e.covariance, o.covariance), f"{tag}: fEstimatedCovariance"
+
+
+@pytest.mark.parametrize("kind,dim,nchains,sync", [(0, 5, 1, 1), (0, 5, 70, 1), (2, 6, 64, 1), (0, 20, 130, 4),
+                                                   (0, 100, 64, 1), (2, 200, 64, 3)])
+def test_hmc_default_tuning_matches_the_ensemble_oracle(gpu, oracle, kind, dim, nchains, sync):
+    """SimpleHMC.C:46-72's call sequence -- Start, then Step with no SetMeanEpsilon and no SetLeapFrog: every chain
+    retunes its step length and leapfrog count by the reversal test (:302-323) and the pooled covariance (:665-858)."""
+    prm = [100.0] if kind == 2 else None
+    e, o = _adaptive_pair(gpu, oracle, dim, nchains, kind, prm, True, sync)
+    x0 = np.ones(dim)
+    e.Start(x0); o.start(x0)
+    assert e.GetMeanEpsilon() == 0.05 and e.GetLeapFrog() == 10
+    nsteps = 40 if dim <= 20 else 12
+    done = 0
+    for chunk in (1, 2, nsteps - 3):
+        e.Step(chunk); o.step(chunk)
+        done += chunk
+        _same_hmc(e, o, f"after {done} steps")
+    assert e.tuning["updates"] >= 1                          # the pooled UpdateErrorMatrix went through
+    assert len(np.unique(e.lane("leapfrog"))) >= 1
+    if nchains == 1:
+        h = oracle.Hmc(dim, kind=kind, params=prm, seed=5, potential_from_gradient=True)
+        h.start(x0)
+        h.run(nsteps)
+        q, _, _ = e.state()
+        assert np.array_equal(h.accepted, q[:, 0])           # one chain, a sync per step: the reference chain
+        assert h.scalars["mean_epsilon"] == e.GetMeanEpsilon() and h.scalars["leapfrog_steps"] == e.GetLeapFrog()
+
+
+@pytest.mark.parametrize("exact", [True, False])
+@pytest.mark.parametrize("dim,nchains,sync", [(20, 70, 1), (100, 64, 2), (300, 64, 1), (500, 96, 1)])
+def test_hmc_quadratic_form_adaptive(gpu, oracle, dim, nchains, sync, exact):
+    """Config 5's likelihood family (quadratic form, analytic gradient) with SetLeapFrog(n) and the step length left to
+    the tuning, in both arithmetic orders (matrix layout kernels)."""
+    err = np.linalg.inv(_spd(dim, 3))
+    e, o = _adaptive_pair(gpu, oracle, dim, nchains, 1, err, exact, sync)
+    x0 = np.full(dim, 0.5)
+    e.Start(x0); o.start(x0)
+    e.SetLeapFrog(6); o.set_leapfrog(6)
+    for k in range(3 if dim < 500 else 2):
+        e.Step(5); o.step(5)
+        _same_hmc(e, o, f"block {k}")
+    assert np.all(e.lane("leapfrog") == -6)
+    assert e.lane("naccept").sum() > 0
+
+
+def test_hmc_fixed_step_can_track_the_covariance(gpu, oracle):
+    dim, n = 8, 64
+    e, o = _adaptive_pair(gpu, oracle, dim, n, 0, None, True, 1)
+    e.TrackCovariance()
+    x0 = np.zeros(dim)
+    e.Start(x0); o.start(x0)
+    e.SetMeanEpsilon(-0.2); o.set_mean_epsilon(-0.2)
+    e.SetLeapFrog(5); o.set_leapfrog(5)
+    e.Step(30); o.step(30)
+    _same_hmc(e, o, "fixed step, tracked covariance")
+    assert np.all(e.lane("mean_epsilon") == -0.2) and e.tuning["trace"] > 0
+
+
+def test_hmc_config5_default_tuning_d500(gpu, oracle):
+    """BASELINE config 5's shape (quadratic form, D = 500) with nothing fixed: automatic leapfrog count (the reversal
+    test runs inside the matrix-layout kernel) and step length, both orders."""
+    dim, n = 500, 64
+    err = np.linalg.inv(_spd(dim, 7))
+    for exact in (True, False):
+        e, o = _adaptive_pair(gpu, oracle, dim, n, 1, err, exact, 1)
+        x0 = np.full(dim, 0.3)
+        e.Start(x0); o.start(x0)
+        e.Step(4); o.step(4)
+        _same_hmc(e, o, f"exact={exact}")
+        assert np.all(e.lane("leapfrog") > 0)

@@ -10,12 +10,18 @@ all-reduce over ranks (RCCL, only when --gpus > 1) and UpdateProposal.  Every
 chain-step does the full reference work: D normals through U, logL, Metropolis
 test, scalar adaptation and the second-moment fold.
 
+After the timed headline (N = 1 only, each with its own warm-up and HIP-event timing, none of it inside
+the headline's timed region) the other single-GPU workloads of BASELINE.json go into `extra`: config 2
+with the header-form TDummyLogLikelihood, config 3, config 4's per-GPU share, config 5.
+
 Prints ONE JSON line (rank 0).
 """
 import argparse
+import gc
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -26,26 +32,64 @@ sys.path.insert(0, ROOT)
 DIM = 50
 CHAINS_PER_GPU = 65536
 WINDOW = 256                      # ensemble steps per launch / adaptation window
-BYTES_PER_CHAIN_STEP = 16 * DIM + 16   # state round-trip model
-HBM_PEAK_GBPS = 8000.0
+HBM_PEAK_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E peak (spec)
+FP64_PEAK_TFLOPS = 78.6           # FP64 vector = FP64 matrix peak (they share one pipe)
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
 
 
-def cpu_baseline(seconds=12.0):
-    """The oracle's single reference chain (oracle_chain, D=50 iso-Gaussian,
-    adaptive) timed on one host core for a bounded sample."""
+def bytes_per_chain_step(dim):
+    """state round-trip model, read x + write x + logL read/write."""
+    return 16 * dim + 16
+
+
+def flops_per_chain_step(dim, like):
+    """proposal D^2 (triangular, multiply + add) + covariance moments D^2 + D + likelihood."""
+    logl = {"iso": 2 * dim, "quadform": 3 * dim * dim, "rosenbrock": 8 * dim}[like]
+    return dim * dim + dim * dim + dim + logl
+
+
+def tdummy_error(dim):
+    """TDummyLogLikelihood::Init() (TDummyLogLikelihood.H:44-142): identity covariance except the (0, D-1) pair."""
+    cov = np.eye(dim)
+    cov[0, dim - 1] = cov[dim - 1, 0] = 0.999999
+    return np.linalg.inv(cov)
+
+
+def cpu_baseline(seconds=8.0):
+    """The oracle's reference chain (oracle_chain = TSimpleMCMC<L, TProposeAdaptiveStep>::Step(false), D=50
+    iso-Gaussian, adaptive) timed on the host for a bounded sample: one core, then every core with an
+    independent chain each (what continue-chain.sh does with processes)."""
     from oracle import oracle as O
     O.build()
-    c = O.Chain(DIM)
-    c.start(np.zeros(DIM))
-    c.run_quiet(20000)            # warm up / first adaptation
-    n, t0 = 0, time.perf_counter()
-    while time.perf_counter() - t0 < seconds:
-        c.run_quiet(50000)
-        n += 50000
-    dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "chain-steps/s", "cores": 1, "kind": "port",
-            "sample": f"{n} Step() calls of one D={DIM} iso-Gaussian chain, TProposeAdaptiveStep, "
-                      f"oracle/oracle_core.h compiled gcc -O2 (no -march), {dt:.1f} s"}
+
+    def run(chain_id, stop_at, out):
+        c = O.Chain(DIM, chain_id=chain_id)
+        c.start(np.zeros(DIM))
+        c.run_quiet(20000)            # warm up / first adaptation
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() < stop_at[0]:
+            c.run_quiet(25000)        # (ctypes releases the GIL for the duration of the C call)
+            n += 25000
+        out[chain_id] = (n, time.perf_counter() - t0)
+
+    res = {}
+    stop = [time.perf_counter() + seconds]
+    run(0, stop, res)
+    n1, dt1 = res[0]
+    # the cores this process may use, at most the 16 a one-GPU box shares out
+    cores = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16)
+    res, stop = {}, [time.perf_counter() + seconds + 1.0]
+    threads = [threading.Thread(target=run, args=(k, stop, res)) for k in range(cores)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    rate_all = sum(n / dt for n, dt in res.values())
+    return {"value": n1 / dt1, "unit": "chain-steps/s", "cores": 1, "kind": "port",
+            "sample": f"{n1} Step(false) calls of one D={DIM} iso-Gaussian chain, TProposeAdaptiveStep, "
+                      f"oracle/oracle_core.h compiled gcc -O2 (no -march), {dt1:.1f} s",
+            "all_cores": {"value": rate_all, "unit": "chain-steps/s", "cores": cores,
+                          "sample": f"{cores} independent chains, one thread each, {seconds:.0f} s"}}
 
 
 ESS_STEPS, ESS_STRIDE = 8192, 16
@@ -66,21 +110,100 @@ def measure_ess(eng, torch, dim):
     return 1.0 / (float(tau.max()) * ESS_STRIDE)
 
 
+def fractions(rate, dim, like):
+    """The two roofline fractions of a Metropolis workload from its chain-steps/s."""
+    return {"hbm_model_GBps": rate * bytes_per_chain_step(dim) / 1e9,
+            "hbm_model_frac": rate * bytes_per_chain_step(dim) / 1e9 / HBM_PEAK_GBPS,
+            "fp64_TFLOPs": rate * flops_per_chain_step(dim, like) / 1e12,
+            "fp64_frac": rate * flops_per_chain_step(dim, like) / 1e12 / FP64_PEAK_TFLOPS}
+
+
+def extra_metropolis(pkg, torch, stream, name, dim, chains, like, like_id, prm, x0, exact, windows, window=WINDOW,
+                     stride=1):
+    """One of the other BASELINE configs: pooled covariance, `window` steps then a sync, timed with HIP events on the
+    engine's stream (device time of the step launches, moment folds included) and with the wall clock (sync included)."""
+    eng = pkg.Engine(dim, chains, likelihood=like_id, likelihood_params=prm, seed=20240607, mode=pkg.MODE_POOLED,
+                     exact=exact, stream=stream.cuda_stream)
+    if dim > 63:
+        eng.set_param("MOMENT_STRIDE", stride)
+    assert eng.Start(x0)
+    eng.Step(window); eng.sync()                      # warm-up window
+    torch.cuda.synchronize()
+    gc.collect(); gc.disable()                        # a full collection of a torch-sized heap stalls the host for ~70 ms
+    evs = []
+    t0 = time.perf_counter()
+    for _ in range(windows):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        eng.Step(window)
+        e1.record(stream)
+        evs.append((e0, e1))
+        eng.sync()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    gc.enable()
+    kms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    rate = chains * window * windows / dt
+    out = {"workload": name, "chain_steps_per_s": rate, "ms_per_window": dt / windows * 1e3, "step_launches_ms": kms,
+           "ms_per_ensemble_step": kms / window, "windows": windows, "window": window,
+           "arithmetic": "reference-order" if exact else "fused (matrix pipe)" if dim > 63 else "fused",
+           "moment_stride": stride,
+           "accept_rate": float(eng.lane("naccept").sum() / (eng.get_param("TOTAL_STEPS") * chains))}
+    out.update(fractions(rate, dim, like))
+    eng.close()
+    return out
+
+
+def extra_hmc(pkg, torch, stream, dim, chains, leapfrog, exact, steps, tuned):
+    """Config 5: TSimpleHMC, header-form TDummyLogLikelihood with its analytic gradient, start at 1 (SimpleHMC.C:45),
+    SetLeapFrog(20).  tuned: the step length is left to the chain (reference default: the covariance fold and the pooled
+    UpdateErrorMatrix run every step, inside the timed region); otherwise SetMeanEpsilon(<0) fixes it."""
+    h = pkg.HmcEngine(dim, chains, likelihood=pkg.LIKE_QUADFORM, likelihood_params=tdummy_error(dim), seed=20240607,
+                      exact=exact, stream=stream.cuda_stream)
+    h.Start(np.ones(dim))
+    if not tuned:
+        h.SetMeanEpsilon(-0.0005)
+    h.SetLeapFrog(leapfrog)
+    h.Step(2)
+    torch.cuda.synchronize()
+    gc.collect(); gc.disable()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record(stream)
+    h.Step(steps)
+    e1.record(stream)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    gc.enable()
+    rate = chains * steps / dt
+    flops = (leapfrog + 1) * 2 * dim * dim + 3 * dim * dim + dim * dim     # SURVEY.md 8(d)
+    out = {"workload": "TSimpleHMC header-form TDummy D=%d, %d chains x %d leapfrog steps, %s step length" %
+                       (dim, chains, leapfrog, "self-tuned" if tuned else "fixed"),
+           "trajectories_per_s": rate, "ms_per_step": dt / steps * 1e3, "device_ms_per_step": e0.elapsed_time(e1) / steps,
+           "steps": steps, "arithmetic": "reference-order" if exact else "fused (matrix pipe)",
+           "fp64_TFLOPs": rate * flops / 1e12, "fp64_frac": rate * flops / 1e12 / FP64_PEAK_TFLOPS,
+           "hbm_model_frac": rate * (32 * dim + 16) / 1e9 / HBM_PEAK_GBPS,
+           "accept_rate": float(h.lane("naccept").mean() / h.lane("trials").mean()),
+           "mean_epsilon_chain0": h.GetMeanEpsilon(), "covariance_updates": h.tuning["updates"]}
+    h.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--chains", type=int, default=CHAINS_PER_GPU)
     ap.add_argument("--window", type=int, default=WINDOW)
     ap.add_argument("--fast", action="store_true", help="fused multiply-add arithmetic (not the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ess", action="store_true", help="skip the ESS trace after the timed region")
+    ap.add_argument("--no-extras", action="store_true", help="skip the other BASELINE configs after the headline")
     ap.add_argument("--frozen", action="store_true", help="diagnostic: frozen covariance, no moment fold")
     ap.add_argument("--dim", type=int, default=DIM, help="diagnostic: other dimension (not the headline)")
     ap.add_argument("--header-tdummy", action="store_true",
-                    help="the other C2 likelihood of SURVEY.md 8(d): header-form TDummyLogLikelihood (quadratic form, Error "
-                         "from Init(), correlation 0.999999 between the first and last coordinate); not the headline")
+                    help="diagnostic: the headline loop on the other C2 likelihood (header-form TDummyLogLikelihood)")
     args = ap.parse_args()
 
     import torch
@@ -101,37 +224,18 @@ def main():
 
     stream = torch.cuda.current_stream()
     dim = args.dim
-    like, like_params = pkg.LIKE_ISO_GAUSS, None
+    like_name, like, like_params = "iso", pkg.LIKE_ISO_GAUSS, None
     if args.header_tdummy:
-        # TDummyLogLikelihood::Init() (TDummyLogLikelihood.H:44-142): identity covariance except the (0, D-1) pair
-        cov = np.eye(dim)
-        cov[0, dim - 1] = cov[dim - 1, 0] = 0.999999
-        like, like_params = pkg.LIKE_QUADFORM, np.linalg.inv(cov)
+        like_name, like, like_params = "quadform", pkg.LIKE_QUADFORM, tdummy_error(dim)
     eng = pkg.Engine(dim, args.chains, likelihood=like, likelihood_params=like_params, seed=20240607,
                      chain_offset=rank * args.chains, device=local,
                      mode=pkg.MODE_FROZEN if args.frozen else pkg.MODE_POOLED,
                      exact=not args.fast, stream=stream.cuda_stream)
     assert eng.Start(np.zeros(dim))
-    mbuf = torch.zeros(eng.moments_size, dtype=torch.float64, device="cuda")
 
-    kernel_ms = []
-
-    def window(timed):
-        if timed:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(stream)
-        eng.Step(args.window)
-        if timed:
-            e1.record(stream)
-            kernel_ms.append((e0, e1))
-        if args.frozen:
-            return
-        eng.reduce_moments()
-        if world > 1:
-            eng.export_moments(mbuf.data_ptr())
-            dist.all_reduce(mbuf)
-            eng.import_moments(mbuf.data_ptr())
-        eng.apply_moments()
+    # the window loop is the package's own (distributed.run_windows): steps, moment reduction, all-reduce over the
+    # ranks when there are several, pooled update; the backend times the step launches with HIP events on its stream
+    backend = pkg.distributed.HipBackend(eng, frozen=args.frozen, time_steps=True, stream=stream)
 
     def fence():
         torch.cuda.synchronize()
@@ -139,14 +243,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        window(False)
+    pkg.distributed.run_windows(backend, args.warmup, args.window)
+    backend.events.clear()
+    gc.collect(); gc.disable()    # no collector pauses inside the timed region
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        window(True)
+    pkg.distributed.run_windows(backend, args.steps, args.window)
     fence()
     dt = time.perf_counter() - t0
+    gc.enable()
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -154,22 +259,25 @@ def main():
 
     chain_steps = float(args.chains) * world * args.window * args.steps
     value = chain_steps / dt
-    kms = float(np.mean([a.elapsed_time(b) for a, b in kernel_ms]))
+    kms = float(np.mean([a.elapsed_time(b) for a, b in backend.events]))
     per_launch = float(args.chains) * args.window
-    bytes_cs = 16 * dim + 16
+    bytes_cs = bytes_per_chain_step(dim)
     achieved = per_launch * bytes_cs / (kms * 1e-3) / 1e9
+    flops_cs = flops_per_chain_step(dim, like_name)
+    fp64_tflops = per_launch * flops_cs / (kms * 1e-3) / 1e12
 
-    # HBM bytes of one launch from the PMC counters (collected in separate rocprofv3 passes,
-    # profiles/r01_pmc_traffic.json); only valid for the configuration it was measured on
-    traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if (os.path.exists(pmc) and dim == DIM and args.chains == CHAINS_PER_GPU and args.window == WINDOW
-            and not args.fast and not args.frozen):
-        traffic = json.load(open(pmc))["hbm_bytes_per_launch"]
+    # HBM bytes of one launch from the PMC counters: collected in separate rocprofv3 --pmc passes over this same
+    # command (tools/profile_bench.sh) and replayed from the committed summary; only valid for the configuration it was
+    # measured on
+    traffic, traffic_source = None, None
+    if (os.path.exists(TRAFFIC_FILE) and dim == DIM and args.chains == CHAINS_PER_GPU and args.window == WINDOW
+            and not args.fast and not args.frozen and not args.header_tdummy):
+        traffic = json.load(open(TRAFFIC_FILE))["hbm_bytes_per_launch"]
+        traffic_source = "replayed from profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)" % os.path.basename(TRAFFIC_FILE)
 
     # ESS per chain-step (outside the timed region): a trace of the adapted ensemble saved
     # every ESS_STRIDE steps through the device-side save path, autocorrelation per dimension
-    # (definition of MakeAutocorrelation.C:127-148) averaged over a subset of chains, Geyer's
+    # (definition of MakeAutocorrelation.C:127-148) pooled over all chains, Geyer's
     # initial positive sequence, minimum over dimensions.
     ess_per_chain_step = None
     if rank == 0 and not args.no_ess:
@@ -195,15 +303,53 @@ def main():
         "ess_per_chain_step": ess_per_chain_step,
         "ess_per_s": (ess_per_chain_step * value) if ess_per_chain_step else None,
         "mean_sigma": float(eng.lane("sigma").mean()),
+        # `achieved` is the north-star's MODEL figure (algorithmic bytes of the state round trip per chain-step / kernel
+        # time), not a measured bandwidth: the state stays in LDS / registers for the 256 steps of a launch and the
+        # kernel is bound by FP64 instruction issue.  measured_hbm_GBps is what the PMC counters saw.
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                     "traffic_unit": "bytes per launch (2 x FETCH_SIZE + WRITE_SIZE)",
+                     "frac": achieved / HBM_PEAK_GBPS,
+                     "model": "algorithmic bytes (16 D + 16 per chain-step, SURVEY.md 8d) / kernel time",
+                     "traffic": traffic, "traffic_unit": "bytes per launch (2 x FETCH_SIZE + WRITE_SIZE)",
+                     "traffic_source": traffic_source,
+                     "measured_hbm_GBps": (traffic / (kms * 1e-3) / 1e9) if traffic else None,
+                     "fp64_TFLOPs": fp64_tflops, "fp64_issue_frac": fp64_tflops / FP64_PEAK_TFLOPS,
+                     "fp64_model": "flops of SURVEY.md 8d (2 D^2 + 3 D) per chain-step / kernel time / 78.6 TFLOP/s",
+                     "limiter": "FP64 instruction issue (one wavefront per SIMD); see profiles/r02_notes.md",
                      "algorithmic_bytes_per_launch": per_launch * bytes_cs,
                      "kernel": "step_kernel<%d,%s,%s,tri,moments>" % (dim, "QUADFORM" if args.header_tdummy else "ISO",
                                                                            "fused" if args.fast else "exact"),
-                     "kernel_ms": kms, "bytes_per_chain_step": bytes_cs,
+                     "kernel_ms": kms, "bytes_per_chain_step": bytes_cs, "flops_per_chain_step": flops_cs,
                      "chain_steps_per_launch": per_launch},
     }
+    eng.close()
+    if rank == 0 and world == 1 and not args.no_extras:
+        extra = {}
+        rng = np.random.default_rng(0)
+        try:
+            extra["c2_header_tdummy"] = extra_metropolis(
+                pkg, torch, stream, "TDummyLogLikelihood header form (quadratic form) D=50, 65 536 chains, pooled", 50,
+                CHAINS_PER_GPU, "quadform", pkg.LIKE_QUADFORM, tdummy_error(50), np.zeros(50), True, 10)
+            x3 = rng.uniform(0.5, 1.5, (200, 16384))                  # SimpleMCMC.C:147
+            for exact in (True, False):
+                extra["c3_rosenbrock_d200_16384_pooled" + ("" if exact else "_fused")] = extra_metropolis(
+                    pkg, torch, stream, "THardLogLikelihood (Rosenbrock) D=200, 16 384 chains, pooled", 200, 16384,
+                    "rosenbrock", pkg.LIKE_ROSENBROCK, [100.0], x3, exact, 3)
+                extra["c4_share_d500_32768_pooled" + ("" if exact else "_fused")] = extra_metropolis(
+                    pkg, torch, stream, "TDummyLogLikelihood README form D=500, 32 768 chains (one GPU's share of config 4), "
+                    "pooled, sync every 256 steps", 500, 32768, "iso", pkg.LIKE_ISO_GAUSS, None, np.zeros(500), exact, 2)
+            extra["c4_share_d500_32768_pooled_header_tdummy"] = extra_metropolis(
+                pkg, torch, stream, "TDummyLogLikelihood header form D=500, 32 768 chains, pooled (the likelihood config 4 "
+                "names, in the reference's order: one serial D^2-term sum per chain)", 500, 32768, "quadform",
+                pkg.LIKE_QUADFORM, tdummy_error(500), np.zeros(500), True, 1)
+            extra["c4_share_d500_32768_pooled_header_tdummy_fused"] = extra_metropolis(
+                pkg, torch, stream, "TDummyLogLikelihood header form D=500, 32 768 chains, pooled", 500, 32768, "quadform",
+                pkg.LIKE_QUADFORM, tdummy_error(500), np.zeros(500), False, 2)
+            extra["c5_hmc_d500_8192_L20"] = extra_hmc(pkg, torch, stream, 500, 8192, 20, True, 3, True)
+            extra["c5_hmc_d500_8192_L20_fused"] = extra_hmc(pkg, torch, stream, 500, 8192, 20, False, 10, True)
+            extra["c5_hmc_d500_8192_L20_fixed_step_fused"] = extra_hmc(pkg, torch, stream, 500, 8192, 20, False, 20, False)
+        except Exception as exc:   # never a reason to lose the headline
+            extra["error"] = repr(exc)
+        out["extra"] = extra
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
     if rank == 0:

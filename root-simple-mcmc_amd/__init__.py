@@ -11,6 +11,7 @@ from ._capi import (LIKE_ISO_GAUSS, LIKE_QUADFORM, LIKE_ROSENBROCK, LIKE_USER, M
                     LIB_PATH, SIGNATURES, load)
 from .engine import Autocorrelation, Engine, HmcEngine, PosteriorMoments, selftest_detmath, selftest_mfma, selftest_mfma_strip  # noqa: F401
 from . import build as _build_mod  # noqa: F401
+from . import distributed  # noqa: F401
 
 
 def build(**kw):

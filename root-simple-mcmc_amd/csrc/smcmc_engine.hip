@@ -93,7 +93,9 @@ struct smcmc_engine {
     double* d_gacc = nullptr;
     double* d_moments = nullptr;
     double* d_chunks = nullptr;
+    double* h_moments = nullptr;   // pinned host copy of the packed moments (read back at every sync)
     double* d_forced = nullptr;
+    double* d_scratch = nullptr;   // dim > 63, quadratic form in reference order: the proposal image its serial sum reads
     ncclComm_t comm = nullptr;     // smcmc_comm_init
     int comm_ranks = 0;
     double* d_proposed = nullptr;  // [dp][npad], allocated by SMCMC_P_KEEP_PROPOSED
@@ -268,12 +270,22 @@ int upload_like(smcmc_engine* h) {
         if ((int)h->like_params.size() != h->dim * h->dim)
             return fail(h, SMCMC_ERR_INVALID, "QUADFORM needs dim*dim likelihood parameters (the Error matrix)");
         const int D = h->dim;
+        if (h->panel_w && h->exact) {
+            // large dimensions, reference order: one lane per chain walks the D^2-term sum of TDummyLogLikelihood.H:24-28
+            // with j innermost; it reads row i of Error^T (scalar loads) and the point from a [dim][chain] image
+            std::vector<double> et((size_t)D * D);
+            for (int i = 0; i < D; ++i)
+                for (int j = 0; j < D; ++j) et[(size_t)i * D + j] = h->like_params[(size_t)j * D + i];
+            if (!h->d_scratch) {
+                HIP_TRY(h, hipMalloc(&h->d_scratch, sizeof(double) * (size_t)h->npad * D));
+                HIP_TRY(h, hipMemsetAsync(h->d_scratch, 0, sizeof(double) * (size_t)h->npad * D, h->stream));
+            }
+            HIP_TRY(h, hipMemcpyAsync(h->d_like, et.data(), et.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+            return SMCMC_OK;
+        }
         if (h->panel_w) {
-            // large dimensions: Error in matrix-operand order for the row sums of panel_mfma_kernel
-            if (h->exact)
-                return fail(h, SMCMC_ERR_UNSUPPORTED,
-                            "the quadratic-form likelihood for dim > 63 runs in the fused order only "
-                            "(SMCMC_P_EXACT_ARITHMETIC = 0): its reference order is one serial D^2-term sum per chain");
+            // large dimensions, fused order: Error in matrix-operand order for the row sums of panel_mfma_kernel
             const int ntiles = (D + 15) / 16, nkq = (D + 3) / 4, nkqp = panel_mfma_nkq_padded(D);
             std::vector<double> eop(panel_mfma_uop_doubles(D), 0.0);
             for (int it = 0; it < ntiles; ++it)
@@ -444,6 +456,7 @@ int launch(smcmc_engine* h, int nsteps, int metropolis, int stride, double* save
         q.save_stride = 1;
         q.has_forced = p.has_forced; q.forced = p.forced;
         q.proposed = p.proposed;
+        q.scratch = h->d_scratch;
         q.uniform = p.uniform; q.scan_dim = p.scan_dim; q.scan_uniform = p.scan_uniform;
         q.scan_a = p.scan_a; q.scan_b = p.scan_b;
         for (int d = 0; d < h->dim; ++d)
@@ -455,8 +468,10 @@ int launch(smcmc_engine* h, int nsteps, int metropolis, int stride, double* save
         if (special_proposal && !exact)
             return fail(h, SMCMC_ERR_UNSUPPORTED,
                         "uniform proposals and the scan of a dimension run in reference-order arithmetic only");
-        if (exact && h->likelihood == SMCMC_LIKE_QUADFORM)
-            return fail(h, SMCMC_ERR_UNSUPPORTED, "the quadratic-form likelihood for dim > 63 runs in the fused order only");
+        if (h->likelihood == SMCMC_LIKE_QUADFORM && exact != h->exact)
+            return fail(h, SMCMC_ERR_UNSUPPORTED,
+                        "the quadratic-form likelihood for dim > 63 with a full (eigen) decomposition needs "
+                        "reference-order arithmetic (SMCMC_P_EXACT_ARITHMETIC = 1)");
         const bool pooled = (h->mode == SMCMC_MODE_POOLED);
         if (pooled && save_x) return fail(h, SMCMC_ERR_UNSUPPORTED, "saving inside a pooled large-dimension launch");
         if (!pooled) { q.save_x = p.save_x; q.save_logl = p.save_logl; q.save_stride = p.save_stride; }
@@ -586,6 +601,7 @@ int smcmc_create(int dim, int nchains, int likelihood, uint64_t seed, uint32_t c
     HIP_TRY(h, hipMalloc(&h->d_c0, sizeof(double) * dp));
     HIP_TRY(h, hipMalloc(&h->d_gacc, sizeof(double) * gacc_doubles(h)));
     HIP_TRY(h, hipMalloc(&h->d_moments, sizeof(double) * npacked(h)));
+    HIP_TRY(h, hipHostMalloc((void**)&h->h_moments, sizeof(double) * npacked(h), hipHostMallocDefault));
     HIP_TRY(h, hipMalloc(&h->d_chunks, sizeof(double) * npacked(h) * ((h->ngroups + kReduceChunk - 1) / kReduceChunk)));
     HIP_TRY(h, hipMemset(h->d_x, 0, sizeof(double) * np * dp));
     HIP_TRY(h, hipMemset(h->d_forced, 0, sizeof(double) * np * dp));
@@ -605,9 +621,9 @@ int smcmc_destroy(smcmc_engine* h) {
     (void)smcmc_comm_destroy(h);
     ON_DEVICE(h);
     if (h->d_x) (void)hipStreamSynchronize(h->stream);
-    (void)hipFree(h->d_x); (void)hipFree(h->d_forced); (void)hipFree(h->d_proposed); (void)hipFree(h->d_uniform); (void)hipFree(h->d_lane_f64); (void)hipFree(h->d_lane_i32);
+    (void)hipFree(h->d_x); (void)hipFree(h->d_forced); (void)hipFree(h->d_proposed); (void)hipFree(h->d_scratch); (void)hipFree(h->d_uniform); (void)hipFree(h->d_lane_f64); (void)hipFree(h->d_lane_i32);
     (void)hipFree(h->d_U); (void)hipFree(h->d_Uop); (void)hipFree(h->d_like); (void)hipFree(h->d_c0); (void)hipFree(h->d_gacc);
-    (void)hipFree(h->d_moments); (void)hipFree(h->d_chunks);
+    (void)hipFree(h->d_moments); (void)hipFree(h->d_chunks); (void)hipHostFree(h->h_moments);
     delete h->prop;
     delete h;
     return SMCMC_OK;
@@ -805,7 +821,7 @@ static int place_chains(smcmc_engine* h, const double* x0, int broadcast, std::v
     HIP_TRY(h, hipMemsetAsync(h->d_lane_f64, 0, sizeof(double) * NP * SMCMC_LANE_F64_COUNT_, h->stream));
     HIP_TRY(h, hipMemsetAsync(h->d_lane_i32, 0, sizeof(int32_t) * NP * SMCMC_LANE_I32_COUNT_, h->stream));
     HIP_TRY(h, hipMemsetAsync(h->d_gacc, 0, sizeof(double) * gacc_doubles(h), h->stream));
-    if (h->panel_w && h->likelihood == SMCMC_LIKE_QUADFORM) {
+    if (h->panel_w && h->likelihood == SMCMC_LIKE_QUADFORM && !h->exact) {
         PanelParams q;
         std::memset(&q, 0, sizeof(q));
         q.nchains = N; q.npad = h->npad; q.dim = D; q.init_only = 1;
@@ -1010,12 +1026,13 @@ int smcmc_read_moments(smcmc_engine* h, double* out) {
 int smcmc_apply_moments(smcmc_engine* h) {
     if (!h || !h->started) return SMCMC_ERR_INVALID;
     ON_DEVICE(h);
-    std::vector<double> M(npacked(h));
-    int st = smcmc_read_moments(h, M.data());
-    if (st) return st;
+    const double* M = h->h_moments;
+    HIP_TRY(h, hipMemcpyAsync(h->h_moments, h->d_moments, npacked(h) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    int st = SMCMC_OK;
     SharedProposal& P = *h->prop;
     if (!(M[npacked(h) - 1] > 0.0)) return SMCMC_OK;
-    P.absorbMoments(M.data(), h->mode == SMCMC_MODE_POOLED);
+    P.absorbMoments(M, h->mode == SMCMC_MODE_POOLED);
     st = update_shared(h);
     if (st) return st;
     return upload_shared(h);

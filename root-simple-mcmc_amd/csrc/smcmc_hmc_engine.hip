@@ -47,6 +47,7 @@ struct smcmc_hmc {
     int sync_every = 1, steps_in_window = 0;
     int fold_nslices = 0, slice_chains = 0;
     double *d_p0 = nullptr, *d_qprev = nullptr, *d_gacc = nullptr, *d_moments = nullptr, *d_zero = nullptr;
+    double* h_moments = nullptr;   // pinned: the packed moments come back every sync
     std::string error;
 };
 
@@ -151,6 +152,7 @@ int hmc_tracking_buffers(smcmc_hmc* h) {
     HMC_TRY(h, hipMalloc(&h->d_gacc, sizeof(double) * hmc_gacc_doubles(h)));
     HMC_TRY(h, hipMalloc(&h->d_moments, sizeof(double) * hmc_npacked(h)));
     HMC_TRY(h, hipMalloc(&h->d_zero, sizeof(double) * h->dim));
+    HMC_TRY(h, hipHostMalloc((void**)&h->h_moments, sizeof(double) * hmc_npacked(h), hipHostMallocDefault));
     HMC_TRY(h, hipMemsetAsync(h->d_p0, 0, vec, h->stream));
     HMC_TRY(h, hipMemsetAsync(h->d_qprev, 0, vec, h->stream));
     HMC_TRY(h, hipMemsetAsync(h->d_gacc, 0, sizeof(double) * hmc_gacc_doubles(h), h->stream));
@@ -167,14 +169,14 @@ int hmc_sync(smcmc_hmc* h) {
     hipError_t e = launch_fold_reduce(h->d_gacc, h->dim, h->fold_nslices, h->d_moments, h->stream);
     if (e != hipSuccess) return hfail(h, SMCMC_ERR_HIP, std::string("fold reduce launch: ") + hipGetErrorString(e));
     HMC_TRY(h, hipMemsetAsync(h->d_gacc, 0, sizeof(double) * hmc_gacc_doubles(h), h->stream));
-    std::vector<double> M(hmc_npacked(h));
-    HMC_TRY(h, hipMemcpyAsync(M.data(), h->d_moments, M.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    const double* M = h->h_moments;
+    HMC_TRY(h, hipMemcpyAsync(h->h_moments, h->d_moments, hmc_npacked(h) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HMC_TRY(h, hipStreamSynchronize(h->stream));
-    if (!(M.back() > 0.0)) return SMCMC_OK;
+    if (!(M[hmc_npacked(h) - 1] > 0.0)) return SMCMC_OK;
     HmcShared& S = *h->shared;
     S.stepCount = (int)h->step_count;
     S.leapfrogZero = (h->leapfrog == 0);
-    S.absorb(M.data(), steps);
+    S.absorb(M, steps);
     if (S.updateErrorMatrix()) {
         const int threads = 256;
         hipLaunchKernelGGL(hmc_retune_kernel, dim3((h->nchains + threads - 1) / threads), dim3(threads), 0, h->stream,
@@ -248,6 +250,7 @@ int smcmc_hmc_destroy(smcmc_hmc* h) {
     (void)hipFree(h->d_E); (void)hipFree(h->d_like); (void)hipFree(h->d_lane_f64); (void)hipFree(h->d_lane_i32);
     (void)hipFree(h->d_p0); (void)hipFree(h->d_qprev); (void)hipFree(h->d_gacc); (void)hipFree(h->d_moments);
     (void)hipFree(h->d_zero);
+    (void)hipHostFree(h->h_moments);
     delete h->shared;
     delete h;
     return SMCMC_OK;

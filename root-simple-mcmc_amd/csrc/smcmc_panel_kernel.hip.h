@@ -41,7 +41,7 @@ struct PanelParams {
     uint32_t step0, chain_offset;
     uint64_t seed;
     const double* Uperm;      // [W][dim][CW]
-    const double* like;       // ROSENBROCK: {b}
+    const double* like;       // ROSENBROCK: {b}; QUADFORM in reference order: Error^T [dim][dim] (like[i * dim + j] = Error(j, i))
     double target, acc_window, asig, max_up, acc_w, acc_wW;
     int per_lane_update, step_rms_window, full_u;
     double* x;                // [dim][npad]
@@ -59,6 +59,7 @@ struct PanelParams {
     int scan_dim;             // fScanDimension (TSimpleMCMC.H:685-704), -1 = off
     int scan_uniform;         // the scanned dimension has a uniform proposal
     double scan_a, scan_b;    // uniform: bounds; Gaussian: centre, sigma
+    double* scratch;          // QUADFORM in reference order: [dim][npad], the proposal as the serial likelihood sum reads it
     double* proposed;         // optional [dim][npad]: the proposal of the launch's last step (fProposed, TSimpleMCMC.H:576);
                               // looked at by the SPECIAL instantiation and by the KEEP / FORCED ones of the matrix-pipe kernel
 };
@@ -67,6 +68,47 @@ template <int W>
 __device__ __forceinline__ size_t step_pitch(size_t np) {
     if constexpr (W == 4) asm volatile("" : "+s"(np));
     return np;
+}
+
+// The quadratic form of TDummyLogLikelihood.H:21-31 in the reference's order, logL -= 0.5*p[i]*Error(j,i)*p[j] with i
+// outer and j inner, is ONE running sum of D^2 terms per chain: nothing inside a chain can be done in parallel, so one
+// lane walks it for its chain, row i of Error^T coming through scalar loads.  Two multiplies and the dependent
+// subtraction per term: at D = 500 that is 750 000 FP64 instructions per chain-step, more than the proposal takes --
+// this is the parity anchor for the likelihood BASELINE config 4 names, not the fast path (the matrix-pipe kernel in
+// the fused order is).  `pc` is the lane's column of a [dim][pitch] image of the point: in the step kernel the LDS
+// image of 32 chains (the 64 chains of a group do not fit: two passes), at Start the state itself.
+// The loads of the point run one group of kQfGroup terms ahead of the arithmetic (two register sets): a term costs two
+// independent multiplies and one dependent subtraction, the memory latency of a group is hidden behind the previous one.
+constexpr int kQfGroup = 32;
+constexpr int kQfLds = 16;   // terms per group of the LDS-fed sum of the step kernel
+template <typename PointPtr>
+__device__ __forceinline__ double quadform_serial(PointPtr pc, size_t NP, cptr_f64 et, int D) {
+    double logl = 0.0;
+    const int ngroups = D / kQfGroup;
+    for (int i = 0; i < D; ++i) {
+        const double h = 0.5 * pc[(size_t)i * NP];
+        const cptr_f64 erow = et + (size_t)i * D;
+        double cur[kQfGroup], nxt[kQfGroup];
+        if (ngroups > 0) {
+#pragma unroll
+            for (int u = 0; u < kQfGroup; ++u) cur[u] = pc[(size_t)u * NP];
+        }
+        for (int g = 0; g < ngroups; ++g) {
+            const int j0 = g * kQfGroup;
+            if (g + 1 < ngroups) {
+#pragma unroll
+                for (int u = 0; u < kQfGroup; ++u) nxt[u] = pc[(size_t)(j0 + kQfGroup + u) * NP];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < kQfGroup; ++u) logl -= h * erow[j0 + u] * cur[u];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < kQfGroup; ++u) cur[u] = nxt[u];
+        }
+        for (int j = ngroups * kQfGroup; j < D; ++j) logl -= h * erow[j] * pc[(size_t)j * NP];
+    }
+    return logl;
 }
 
 // SPECIAL = the instantiation that also knows uniform per-dimension proposals and the scan of one dimension
@@ -286,6 +328,15 @@ __global__ void __launch_bounds__(W * kWave) panel_step_kernel(const PanelParams
             }
         }
 
+        if constexpr (LIKE == SMCMC_LIKE_QUADFORM) {
+            // the whole proposal where one lane per chain can read it
+#pragma unroll
+            for (int jl = 0; jl < CW; ++jl) {
+                const int j = jl * W + w;
+                if (j < D) p.scratch[(size_t)j * NP + chain] = xp[jl];
+            }
+        }
+
         // ---- gather: wavefront 0 walks the proposal in dimension order ----
         double sqr = 0.0, lsum = 0.0, prev_p = 0.0;
         const double rb = (LIKE == SMCMC_LIKE_ROSENBROCK) ? likep[0] : 0.0;
@@ -321,6 +372,8 @@ __global__ void __launch_bounds__(W * kWave) panel_step_kernel(const PanelParams
                                 const double t = -0.5 * pj;
                                 if constexpr (EXACT) lsum += t * pj;
                                 else lsum = SMCMC_FMA(t, pj, lsum);
+                            } else if constexpr (LIKE == SMCMC_LIKE_QUADFORM) {
+                                (void)pj;   // summed below, from the global image
                             } else {
                                 // term i = j-1 of THardLogLikelihood.H:60-64 needs p[j-1] and p[j]
                                 if (j > 0) {
@@ -340,6 +393,69 @@ __global__ void __launch_bounds__(W * kWave) panel_step_kernel(const PanelParams
                         }
                     }
                 }
+            }
+        }
+
+        if constexpr (LIKE == SMCMC_LIKE_QUADFORM) {
+            // the proposal of 32 chains at a time as pl[j][32] in the (now idle) staging area of U: 256-byte rows, a
+            // conflict-free ds_read_b64 per term; lanes 32 * pass .. + 31 of wavefront 0 sum their chains
+            // Row i of Error^T (wave-uniform) is staged through LDS by all the threads of the workgroup, one row ahead
+            // of the summing lanes (rbuf, free at this point, holds two rows): scalar loads would stall the sum on a
+            // scalar-cache miss every eight terms.
+            static_assert(W * kPanelRows * CW >= W * CW * 32, "the LDS image of 32 chains must fit the U staging area");
+            static_assert(kPanelRows * kWave >= 2 * W * CW, "two rows of Error must fit the normals' buffer");
+            constexpr int kERow = W * CW;   // doubles per staged row (>= D)
+            for (int pass = 0; pass < 2; ++pass) {
+                __syncthreads();
+                if ((lane >> 5) == pass) {
+                    for (int j = w; j < D; j += W) ulds[j * 32 + (lane & 31)] = p.scratch[(size_t)j * NP + chain];
+                }
+                for (int k = threadIdx.x; k < D; k += W * kWave) rbuf[k] = p.like[k];
+                __syncthreads();
+                const bool summing = (w == 0) && ((lane >> 5) == pass);
+                const double* pl = ulds + (lane & 31);
+                double acc = 0.0;
+                for (int i = 0; i < D; ++i) {
+                    // the next row: loaded before the sum (D <= W * kWave: one element per thread), stored after it
+                    double enext = 0.0;
+                    if (i + 1 < D && (int)threadIdx.x < D) enext = p.like[(size_t)(i + 1) * D + threadIdx.x];
+                    if (summing) {
+                        const double h = 0.5 * pl[i * 32];
+                        const double* er = rbuf + (i & 1) * kERow;
+                        // the LDS reads of a group of kQfLds terms are all issued before its arithmetic, the next group's
+                        // before this group's arithmetic (two register sets): the scheduler, left alone, pairs every read
+                        // with its use and the sum crawls at one LDS latency per two terms
+                        constexpr int G = kQfLds;
+                        const int ngr = D / G;
+                        double pa[G], pb[G];
+                        f64x2 ea[G / 2], eb[G / 2];
+                        auto fetch = [&](int j0, double (&pv)[G], f64x2 (&ev)[G / 2]) {
+#pragma unroll
+                            for (int u = 0; u < G; ++u) pv[u] = pl[(j0 + u) * 32];
+#pragma unroll
+                            for (int u = 0; u < G / 2; ++u) ev[u] = *(const f64x2*)(er + j0 + 2 * u);
+                        };
+                        auto fold = [&](const double (&pv)[G], const f64x2 (&ev)[G / 2]) {
+#pragma unroll
+                            for (int u = 0; u < G; ++u) acc -= h * ev[u / 2][u & 1] * pv[u];
+                        };
+                        if (ngr > 0) fetch(0, pa, ea);
+                        for (int g = 0; g < ngr; g += 2) {
+                            if (g + 1 < ngr) fetch((g + 1) * G, pb, eb);
+                            __builtin_amdgcn_sched_barrier(0);
+                            fold(pa, ea);
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (g + 2 < ngr) fetch((g + 2) * G, pa, ea);
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (g + 1 < ngr) fold(pb, eb);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        for (int j = ngr * G; j < D; ++j) acc -= h * er[j] * pl[j * 32];
+                    }
+                    if (i + 1 < D && (int)threadIdx.x < D) rbuf[((i + 1) & 1) * kERow + threadIdx.x] = enext;
+                    __syncthreads();
+                }
+                if (summing) lsum = acc;
             }
         }
 
@@ -380,11 +496,17 @@ __global__ void __launch_bounds__(W * kWave) panel_step_kernel(const PanelParams
         last_accept = take ? 1 : 0;
         if (take) ++naccept;
         logl = new_logl;
+        // QUADFORM: the proposal went to its global image before the likelihood and is taken from there, so that the
+        // registers that held it are free during the serial sum
+        auto proposal = [&](int jl, int j) {
+            if constexpr (LIKE == SMCMC_LIKE_QUADFORM) return p.scratch[(size_t)j * NP + chain];
+            else return xp[jl];
+        };
         if (take) {
 #pragma unroll
             for (int jl = 0; jl < CW; ++jl) {
                 const int j = jl * W + w;
-                if (j < D) p.x[(size_t)j * (W == 4 ? NPl : NP) + chain] = xp[jl];
+                if (j < D) p.x[(size_t)j * (W == 4 ? NPl : NP) + chain] = proposal(jl, j);
             }
         }
         if (p.save_x != nullptr && ((s + 1) % p.save_stride) == 0 && active) {
@@ -392,7 +514,7 @@ __global__ void __launch_bounds__(W * kWave) panel_step_kernel(const PanelParams
 #pragma unroll
             for (int jl = 0; jl < CW; ++jl) {
                 const int j = jl * W + w;
-                if (j < D) p.save_x[(slot * (size_t)D + (size_t)j) * (W == 4 ? NPl : NP) + chain] = take ? xp[jl] : p.x[(size_t)j * (W == 4 ? NPl : NP) + chain];
+                if (j < D) p.save_x[(slot * (size_t)D + (size_t)j) * (W == 4 ? NPl : NP) + chain] = take ? proposal(jl, j) : p.x[(size_t)j * (W == 4 ? NPl : NP) + chain];
             }
             if (w == 0) p.save_logl[slot * (W == 4 ? NPl : NP) + chain] = logl;
         }
@@ -433,6 +555,9 @@ __global__ void start_loglike_kernel(const double* __restrict__ x, int nchains, 
             if constexpr (EXACT) lsum += t * pi;
             else lsum = SMCMC_FMA(t, pi, lsum);
         }
+    } else if constexpr (LIKE == SMCMC_LIKE_QUADFORM) {
+        static_assert(EXACT || LIKE != SMCMC_LIKE_QUADFORM, "the fused order of the quadratic form is the matrix-pipe kernel's");
+        lsum = quadform_serial(x + chain, npad, as_const(like), D);
     } else {
         const double rb = like[0];
         double prev = x[chain];

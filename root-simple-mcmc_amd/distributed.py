@@ -12,15 +12,29 @@ import numpy as np
 
 
 class HipBackend:
-    """Adapter: one Engine on this rank's GPU, moments exchanged through a device tensor."""
+    """Adapter: one Engine on this rank's GPU, moments exchanged through a device tensor.
 
-    def __init__(self, engine):
+    frozen: the covariance does not adapt, so there is nothing to exchange (run_windows only steps).
+    time_steps: bracket every step launch with HIP events on `stream` (the torch stream the engine launches on);
+    `events` then holds one (start, end) pair per window for the caller to read after a synchronize."""
+
+    def __init__(self, engine, frozen=False, time_steps=False, stream=None):
         import torch
         self.engine = engine
+        self.frozen = frozen
         self.buffer = torch.zeros(engine.moments_size, dtype=torch.float64, device="cuda")
+        self.time_steps, self.stream, self.events = time_steps, stream, []
 
     def step(self, nsteps):
+        if not self.time_steps:
+            self.engine.Step(nsteps)
+            return
+        import torch
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(self.stream)
         self.engine.Step(nsteps)
+        e1.record(self.stream)
+        self.events.append((e0, e1))
 
     def moments_out(self):
         self.engine.reduce_moments()
@@ -50,6 +64,8 @@ def run_windows(backend, nwindows, window, group=None):
     distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
     for _ in range(nwindows):
         backend.step(window)
+        if getattr(backend, "frozen", False):
+            continue
         m = backend.moments_out()
         if distributed:
             dist.all_reduce(m, op=dist.ReduceOp.SUM, group=group)

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.gpu
 def test_bench_line_has_the_contract_fields(gpu):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--chains", "4096",
-                        "--no-cpu-baseline", "--no-ess"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+                        "--no-cpu-baseline", "--no-ess", "--no-extras"], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
@@ -24,7 +24,7 @@ def test_bench_line_has_the_contract_fields(gpu):
     assert out["higher_is_better"] is True and out["scaling"] == "weak" and out["vs_baseline"] is None
     assert out["dtype"] == "f64" and out["data"] == "synthetic" and "workload" in out["config"]
     roof = out["roofline"]
-    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "fp64_issue_frac", "measured_hbm_GBps"):
         assert key in roof, key
     assert roof["bound"] == "hbm" and roof["peak"] == 8000.0 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-12
     # value = chain-steps of the timed windows / wall time

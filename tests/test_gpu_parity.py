@@ -454,11 +454,39 @@ def test_dimension_limit_is_reported(gpu):
     assert err.value.status == 5   # SMCMC_ERR_UNSUPPORTED, no host fallback
 
 
-def test_quadratic_form_at_large_dim_needs_the_fused_order(gpu, oracle):
-    e = gpu.Engine(100, 64, likelihood=1, likelihood_params=oracle.like_params(1, 100))
-    with pytest.raises(gpu.SmcmcError) as err:
-        e.Start(np.zeros(100))
-    assert err.value.status == 5   # SMCMC_ERR_UNSUPPORTED
+@pytest.mark.parametrize("mode", ["frozen", "pooled"])
+@pytest.mark.parametrize("dim,nchains,steps", [(64, 70, 10), (100, 96, 8), (300, 64, 5), (500, 64, 4)])
+def test_quadratic_form_at_large_dim_in_the_reference_order(gpu, oracle, mode, dim, nchains, steps):
+    """TDummyLogLikelihood.H:21-31 for D > 63 exactly as the reference sums it -- logL -= 0.5*p[i]*Error(j,i)*p[j], i
+    outer, j inner, one running sum of D^2 terms per chain (a lane walks it) -- with Error from Init() (the pair
+    (0, D-1) correlated by 0.999999: cancellations at the 5E+5 scale make the order visible in the last bits)."""
+    m = gpu.MODE_FROZEN if mode == "frozen" else gpu.MODE_POOLED
+    e, o = _pair(gpu, oracle, dim, nchains, 1, m, True)
+    if mode == "pooled":
+        e.set_param("MOMENT_STRIDE", 2)
+        o.set_moment_grouping(int(e.get_param("MOMENT_GROUP")), 2)
+    x0 = np.full(dim, 0.05)
+    assert e.Start(x0) and o.start(x0)
+    _assert_same_state(e, o, "after start")
+    for w in range(2):
+        e.Step(steps); o.step(steps)
+        _assert_same_state(e, o, f"{mode} window {w}")
+        if mode == "pooled":
+            e.sync(); o.sync()
+            assert np.array_equal(e.decomposition, o.decomposition)
+    assert e.lane("naccept").sum() > 0
+
+
+def test_quadratic_form_orders_agree_to_rounding(gpu, oracle):
+    """Reference order (serial sum) and fused order (matrix pipe, row-wise association) of the same likelihood."""
+    dim, n = 200, 64
+    prm = oracle.like_params(1, dim)
+    out = []
+    for exact in (True, False):
+        e = gpu.Engine(dim, n, likelihood=1, likelihood_params=prm, mode=gpu.MODE_FROZEN, exact=exact)
+        assert e.Start(np.full(dim, 0.05))
+        out.append(e.GetAcceptedLogLikelihood())
+    assert np.allclose(out[0], out[1], rtol=1e-9) and np.all(out[0] < 0)
 
 
 # ---------------------------------------------------------------- uniform dimensions and scan

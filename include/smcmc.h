@@ -48,7 +48,15 @@ typedef enum {
      * with `python root-simple-mcmc_amd/build.py --user-likelihood my_likelihood.hip.h` carries it
      * (INTEGRATION.md); other builds answer SMCMC_ERR_UNSUPPORTED.  dim <= 63; params = whatever the
      * function reads (at most dim_padded^2 doubles). */
-    SMCMC_LIKE_USER = 3
+    SMCMC_LIKE_USER = 3,
+    /* The reference's stress targets (Metropolis engine only; they have no gradient, TSimpleHMC.H:85-89):
+     * TAsymLogLikelihood.H:20-31, params = {positiveSlope, negativeSlope} (default -1, 100);
+     * THorrificLogLikelihood.H:26-38 (no parameters);
+     * example4/TConstrainedLikelihood.H:26-46, params = {SummedValues, SummedConstraint, ExpectedValues[dim],
+     * PriorConstraints[dim]}, dim <= 63. */
+    SMCMC_LIKE_ASYM = 4,
+    SMCMC_LIKE_HORRIFIC = 5,
+    SMCMC_LIKE_CONSTRAINED = 6
 } smcmc_likelihood;
 
 /* How the proposal covariance adapts over the ensemble. */
@@ -267,6 +275,11 @@ int smcmc_hmc_get_leapfrog(smcmc_hmc* h, int* steps);                   /* fLeap
  * one step is the reference chain.  Runs whenever the step length or the leapfrog count is not fixed;
  * smcmc_hmc_set_track_covariance(h, 1) keeps it running for a fixed step too (the Trace / Orbit outputs). */
 int smcmc_hmc_set_sync_interval(smcmc_hmc* h, int steps);
+/* Step(save, gradientType), TSimpleHMC.H:279 / PotentialGradient :467-532.  0, 1, 4: the likelihood's own gradient;
+ * 2: CovariantGradient (:447-454) from the pooled running covariance (tracked from then on); 3: FiniteDifferenceGradient
+ * (:417-444); 5: zero.  Types 2, 3, 5 need reference-order arithmetic (SMCMC_ERR_UNSUPPORTED otherwise). */
+int smcmc_hmc_set_gradient_type(smcmc_hmc* h, int type);
+int smcmc_hmc_get_gradient_type(const smcmc_hmc* h);
 int smcmc_hmc_set_track_covariance(smcmc_hmc* h, int on);
 int smcmc_hmc_moment_group(const smcmc_hmc* h);
 int smcmc_hmc_sync(smcmc_hmc* h);                                        /* the pooled update now (end of a run) */

@@ -148,7 +148,8 @@ void oracle_ensemble_set_sigma(oracle_ensemble* e, double s) {
 
 static double ens_like(const oracle_ensemble* e, const double* p) {
     const int n = e->dim;
-    if (e->exact) return oracle_like(e->like_kind, n, p, e->like_params);
+    /* the stress likelihoods (asymmetric, horrific, constrained) have no fused form: the same arithmetic in both orders */
+    if (e->exact || e->like_kind >= ORACLE_LIKE_ASYM) return oracle_like(e->like_kind, n, p, e->like_params);
     /* fused order (the "fast" arithmetic of the HIP kernels) */
     double logl = 0.0;
     switch (e->like_kind) {

@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "_build", "libsmcmc_oracle.so")
 
-LIKE_ISO, LIKE_QUADFORM, LIKE_ROSENBROCK = 0, 1, 2
+LIKE_ISO, LIKE_QUADFORM, LIKE_ROSENBROCK, LIKE_ASYM, LIKE_HORRIFIC, LIKE_CONSTRAINED = 0, 1, 2, 4, 5, 6
 MODE_FROZEN, MODE_POOLED = 0, 1
 
 _dp = C.POINTER(C.c_double)
@@ -186,7 +186,22 @@ def like_params(kind, dim, params=None):
         return dummy_error_matrix(dim)[1].ravel()
     if kind == LIKE_ROSENBROCK:
         return np.array([100.0])
+    if kind == LIKE_ASYM:
+        return np.array([-1.0, 100.0])           # TAsymLogLikelihood.H:17-18
+    if kind == LIKE_CONSTRAINED:
+        return constrained_params(dim)
     return np.zeros(0)
+
+
+def constrained_params(dim=25):
+    """example4/TConstrainedLikelihood.H:55-110 (Init): the sum 1902 +- 16, 24 values 76 +- 8 % and one 80 +- 2; for another
+    dimension the same pattern (the last value is the tight one).  Layout {SummedValues, SummedConstraint, Expected[D],
+    Prior[D]}."""
+    expected = np.full(dim, 76.0)
+    prior = np.full(dim, 76.0 * 0.08)
+    expected[dim - 1], prior[dim - 1] = 80.0, 2.0
+    total = 1902.0 if dim == 25 else float(expected.sum()) - 2.0
+    return np.concatenate([[total, 16.0], expected, prior])
 
 
 SCALAR_NAMES = ["accepted_logl", "proposed_logl", "sigma", "acceptance", "acceptance_trials",
@@ -490,8 +505,13 @@ class HmcEnsemble:
         prm = like_params(kind, dim, params)
         self._h = lib().oracle_hmc_ensemble_create(nchains, dim, kind, _p(prm) if prm.size else None, prm.size, seed,
                                                    chain_offset, group, sync_every)
-        lib().oracle_hmc_ensemble_configure(self._h, alpha, int(potential_from_gradient), int(fused_gradient),
-                                            int(gradient_type))
+        self._config = [alpha, int(potential_from_gradient), int(fused_gradient), int(gradient_type)]
+        lib().oracle_hmc_ensemble_configure(self._h, *self._config)
+
+    def set_gradient_type(self, t):
+        """Step(save, gradientType) for the steps that follow (TSimpleHMC.H:279, 467-532)."""
+        self._config[3] = int(t)
+        lib().oracle_hmc_ensemble_configure(self._h, *self._config)
 
     def __del__(self):
         if getattr(self, "_h", None):

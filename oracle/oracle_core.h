@@ -30,7 +30,9 @@
 #include "../include/smcmc_detmath.h"
 #include "oracle_linalg.h"
 
-enum { ORACLE_LIKE_ISO = 0, ORACLE_LIKE_QUADFORM = 1, ORACLE_LIKE_ROSENBROCK = 2 };
+/* 3 is the engine's SMCMC_LIKE_USER (a likelihood compiled in from user source) */
+enum { ORACLE_LIKE_ISO = 0, ORACLE_LIKE_QUADFORM = 1, ORACLE_LIKE_ROSENBROCK = 2, ORACLE_LIKE_ASYM = 4,
+       ORACLE_LIKE_HORRIFIC = 5, ORACLE_LIKE_CONSTRAINED = 6 };
 
 /* ---- likelihood functors ------------------------------------------------ */
 
@@ -61,9 +63,55 @@ static double oracle_like_rosenbrock(int dim, const double* p, double rosen_b) {
     return logl;
 }
 
+/* TAsymLogLikelihood.H:20-31: a = p[i]; a *= (a < 0) ? negativeSlope : positiveSlope; logL += a.
+ * params = {positiveSlope, negativeSlope}, the reference's constants (-1, 100) by default (:17-18). */
+static double oracle_like_asym(int dim, const double* p, const double* params, int nparams) {
+    const double positive = (nparams >= 2) ? params[0] : -1.0, negative = (nparams >= 2) ? params[1] : 100.0;
+    double logl = 0.0;
+    for (int i = 0; i < dim; ++i) {
+        double a = p[i];
+        if (a < 0.0) a *= negative; else a *= positive;
+        logl += a;
+    }
+    return logl;
+}
+
+/* THorrificLogLikelihood.H:26-38: -1E+30 outside the unit box, else -0.5 (sum p / sqrt(D 4/12))^2 / 0.01^2 */
+static double oracle_like_horrific(int dim, const double* p) {
+    const double sigma = 0.01;
+    double logl = 0.0;
+    for (int i = 0; i < dim; ++i) {
+        if (fabs(p[i]) > 1.0) return -1E+30;
+        logl += p[i];
+    }
+    double natural_sigma = sqrt(dim * 4.0 / 12.0);
+    logl /= natural_sigma;
+    logl = -0.5 * logl * logl / sigma / sigma;
+    return logl;
+}
+
+/* example4/TConstrainedLikelihood.H:26-46: the sum constrained to SummedValues +- SummedConstraint, every value to
+ * ExpectedValues[i] +- PriorConstraints[i].  params = {SummedValues, SummedConstraint, Expected[D], Prior[D]}. */
+static double oracle_like_constrained(int dim, const double* p, const double* params) {
+    double logl = 0.0;
+    double sum = 0.0;
+    for (int i = 0; i < dim; ++i) sum += p[i];
+    sum = (sum - params[0]) / params[1];
+    logl -= 0.5 * sum * sum;
+    for (int i = 0; i < dim; ++i) {
+        double v = p[i] - params[2 + i];
+        v /= params[2 + dim + i];
+        logl -= 0.5 * v * v;
+    }
+    return logl;
+}
+
 static double oracle_like(int kind, int dim, const double* p, const double* params) {
     switch (kind) {
         case ORACLE_LIKE_ISO: return oracle_like_iso(dim, p);
+        case ORACLE_LIKE_ASYM: return oracle_like_asym(dim, p, params, params ? 2 : 0);
+        case ORACLE_LIKE_HORRIFIC: return oracle_like_horrific(dim, p);
+        case ORACLE_LIKE_CONSTRAINED: return oracle_like_constrained(dim, p, params);
         case ORACLE_LIKE_QUADFORM: return oracle_like_quadform(dim, p, params);
         default: return oracle_like_rosenbrock(dim, p, params ? params[0] : 100.0);
     }

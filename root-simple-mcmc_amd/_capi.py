@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(HERE, "lib", "libsmcmc_amd.so")
 OK, ERR_INVALID, ERR_LOGIC, ERR_RUNTIME, ERR_BAD_START, ERR_UNSUPPORTED, ERR_HIP, ERR_NO_DEVICE = range(8)
 
 LIKE_ISO_GAUSS, LIKE_QUADFORM, LIKE_ROSENBROCK, LIKE_USER = 0, 1, 2, 3
+LIKE_ASYM, LIKE_HORRIFIC, LIKE_CONSTRAINED = 4, 5, 6   # the reference's stress targets (smcmc.h)
 MODE_FROZEN, MODE_POOLED = 0, 1
 
 PARAMS = ["COVARIANCE_WINDOW", "COVARIANCE_DEWEIGHT", "ACCEPTANCE_WINDOW", "ACCEPTANCE_DEWEIGHT",
@@ -106,6 +107,8 @@ SIGNATURES = {
     "smcmc_hmc_get_leapfrog": (C.c_int, [_H, C.POINTER(C.c_int)]),
     "smcmc_hmc_set_sync_interval": (C.c_int, [_H, C.c_int]),
     "smcmc_hmc_set_track_covariance": (C.c_int, [_H, C.c_int]),
+    "smcmc_hmc_set_gradient_type": (C.c_int, [_H, C.c_int]),
+    "smcmc_hmc_get_gradient_type": (C.c_int, [_H]),
     "smcmc_hmc_moment_group": (C.c_int, [_H]),
     "smcmc_hmc_sync": (C.c_int, [_H]),
     "smcmc_hmc_get_tuning": (C.c_int, [_H, _dp]),

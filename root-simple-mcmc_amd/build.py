@@ -27,6 +27,8 @@ ARCH = "gfx950"
 FLAGS = ["-std=c++17", "-O3", "-fPIC", "-ffp-contract=off", f"--offload-arch={ARCH}",
          "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", f"-I{INCLUDE}", f"-I{CSRC}"]
 LIKELIHOODS = (0, 1, 2)
+STRESS_LIKELIHOODS = (4, 5, 6)   # SMCMC_LIKE_ASYM / HORRIFIC / CONSTRAINED: built for two families only (launch_step)
+STRESS_DP = (31, 63)
 
 
 def dp_list():
@@ -51,6 +53,9 @@ def _units(user_flag=None):
     for dp in dp_list():
         for like in LIKELIHOODS:
             units.append(("smcmc_inst.hip", [f"-DSMCMC_DP={dp}", f"-DSMCMC_LIKE={like}"], f"inst_dp{dp}_l{like}"))
+    for dp in STRESS_DP:
+        for like in STRESS_LIKELIHOODS:
+            units.append(("smcmc_inst.hip", [f"-DSMCMC_DP={dp}", f"-DSMCMC_LIKE={like}"], f"inst_dp{dp}_l{like}"))
     for w in (4, 8):
         units.append(("smcmc_panel_inst.hip", [f"-DSMCMC_PANEL_W={w}"], f"panel_w{w}"))
         units.append(("smcmc_hmc_inst.hip", [f"-DSMCMC_PANEL_W={w}"], f"hmc_w{w}"))
@@ -63,12 +68,27 @@ def _units(user_flag=None):
 _EXTRA = {"files": []}   # the user likelihood header, part of the stamps of the units built with it
 
 
+def _closure(path, seen):
+    """`path` and the project headers it includes, transitively (quoted includes found in csrc/ or include/)."""
+    if path in seen:
+        return
+    seen.add(path)
+    for name in re.findall(r'^\s*#\s*include\s+"([^"]+)"', open(path).read(), flags=re.M):
+        for base in (os.path.dirname(path), CSRC, INCLUDE):
+            cand = os.path.join(base, name)
+            if os.path.exists(cand):
+                _closure(os.path.abspath(cand), seen)
+                break
+
+
 def _stamp(src, defs):
     h = hashlib.sha256()
     h.update(" ".join(FLAGS + defs).encode())
     extra = _EXTRA["files"] if any("SMCMC_USER_LIKELIHOOD" in d for d in defs) else []
-    for path in [os.path.join(CSRC, src)] + _headers() + extra:
-        h.update(path.encode())
+    deps = set()
+    _closure(os.path.abspath(os.path.join(CSRC, src)), deps)
+    for path in sorted(deps) + extra:
+        h.update(os.path.basename(path).encode())
         h.update(open(path, "rb").read())
     return h.hexdigest()
 
@@ -79,6 +99,11 @@ def _compile(unit):
     stamp_file = obj + ".stamp"
     stamp = _stamp(src, defs)
     if os.path.exists(obj) and os.path.exists(stamp_file) and open(stamp_file).read() == stamp:
+        return obj, False
+    # development aid: SMCMC_BUILD_ONLY=engine,inst_dp50_l0 recompiles just those units and links the rest as they
+    # are (stale objects keep their old stamp and are rebuilt by the next full build)
+    only = os.environ.get("SMCMC_BUILD_ONLY")
+    if only and name not in only.split(",") and os.path.exists(obj):
         return obj, False
     cmd = [HIPCC] + FLAGS + defs + ["-c", os.path.join(CSRC, src), "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)

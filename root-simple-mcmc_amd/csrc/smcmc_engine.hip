@@ -32,9 +32,14 @@ constexpr int kDPList[] = {SMCMC_FOR_EACH_DP(SMCMC_DP_ENTRY)};
 #undef SMCMC_DP_ENTRY
 constexpr int kNumDP = sizeof(kDPList) / sizeof(kDPList[0]);
 
-int pick_dp(int dim) {
+bool stress_likelihood(int like) {
+    return like == SMCMC_LIKE_ASYM || like == SMCMC_LIKE_HORRIFIC || like == SMCMC_LIKE_CONSTRAINED;
+}
+
+int pick_dp(int dim, int like) {
+    // the stress likelihoods are instantiated for the 31- and 63-wide families only (launch_step)
     for (int i = 0; i < kNumDP; ++i)
-        if (dim <= kDPList[i]) return kDPList[i];
+        if (dim <= kDPList[i] && (!stress_likelihood(like) || kDPList[i] == 31 || kDPList[i] == 63)) return kDPList[i];
     return -1;
 }
 
@@ -305,6 +310,24 @@ int upload_like(smcmc_engine* h) {
             for (int j = 0; j < D; ++j) et[(size_t)i * D + j] = h->like_params[(size_t)j * D + i];
         return upload_padded(h, et.data(), h->d_like);
     }
+    if (stress_likelihood(h->likelihood)) {
+        std::vector<double> prm;
+        if (h->likelihood == SMCMC_LIKE_ASYM) {
+            prm = {-1.0, 100.0};                                   // TAsymLogLikelihood.H:21-22
+            if (h->like_params.size() == 2) prm = h->like_params;
+            else if (!h->like_params.empty()) return fail(h, SMCMC_ERR_INVALID, "ASYM takes {positiveSlope, negativeSlope}");
+        } else if (h->likelihood == SMCMC_LIKE_CONSTRAINED) {
+            if ((int)h->like_params.size() != 2 + 2 * h->dim)
+                return fail(h, SMCMC_ERR_INVALID,
+                            "CONSTRAINED needs {SummedValues, SummedConstraint, ExpectedValues[dim], PriorConstraints[dim]}");
+            prm = h->like_params;
+        } else {
+            prm = {0.0};
+        }
+        HIP_TRY(h, hipMemcpyAsync(h->d_like, prm.data(), prm.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        return SMCMC_OK;
+    }
     if (h->likelihood == SMCMC_LIKE_USER) {
         if (h->like_params.size() > (size_t)h->dp * h->dp)
             return fail(h, SMCMC_ERR_INVALID, "a user likelihood takes at most dim_padded^2 parameters");
@@ -468,6 +491,10 @@ int launch(smcmc_engine* h, int nsteps, int metropolis, int stride, double* save
         if (special_proposal && !exact)
             return fail(h, SMCMC_ERR_UNSUPPORTED,
                         "uniform proposals and the scan of a dimension run in reference-order arithmetic only");
+        if (stress_likelihood(h->likelihood) && !exact)
+            return fail(h, SMCMC_ERR_UNSUPPORTED,
+                        "the stress likelihoods (ASYM, HORRIFIC) for dim > 63 run in reference-order arithmetic only "
+                        "(SMCMC_P_EXACT_ARITHMETIC = 1)");
         if (h->likelihood == SMCMC_LIKE_QUADFORM && exact != h->exact)
             return fail(h, SMCMC_ERR_UNSUPPORTED,
                         "the quadratic-form likelihood for dim > 63 with a full (eigen) decomposition needs "
@@ -554,7 +581,7 @@ int smcmc_create(int dim, int nchains, int likelihood, uint64_t seed, uint32_t c
     if (!out) return SMCMC_ERR_INVALID;
     *out = nullptr;
     if (dim < 1 || nchains < 1) return SMCMC_ERR_INVALID;
-    if (likelihood < SMCMC_LIKE_ISO_GAUSS || likelihood > SMCMC_LIKE_USER) return SMCMC_ERR_INVALID;
+    if (likelihood < SMCMC_LIKE_ISO_GAUSS || likelihood > SMCMC_LIKE_CONSTRAINED) return SMCMC_ERR_INVALID;
 #ifndef SMCMC_USER_LIKELIHOOD
     if (likelihood == SMCMC_LIKE_USER) return SMCMC_ERR_UNSUPPORTED;   // this build carries no user likelihood
 #endif
@@ -562,15 +589,16 @@ int smcmc_create(int dim, int nchains, int likelihood, uint64_t seed, uint32_t c
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return SMCMC_ERR_NO_DEVICE;
     if (device < 0 || device >= ndev) return SMCMC_ERR_NO_DEVICE;
-    int dp = pick_dp(dim);
+    int dp = pick_dp(dim, likelihood);
     int panel_w = 0;
     if (dp < 0) {
+        if (likelihood == SMCMC_LIKE_CONSTRAINED) return SMCMC_ERR_UNSUPPORTED;   // per-dimension parameters: dim <= 63
         // large dimensions: a workgroup of 4 or 8 wavefronts per 64-chain group (smcmc_panel_kernel.hip.h)
         if (dim <= 4 * kPanelCW) panel_w = 4;
         else if (dim <= 8 * kPanelCW) panel_w = 8;
         else return SMCMC_ERR_UNSUPPORTED;
         if (likelihood == SMCMC_LIKE_USER) return SMCMC_ERR_UNSUPPORTED;   // user likelihoods: dim <= 63
-        dp = dim;   // QUADFORM here runs in the fused order only (checked at Start)
+        dp = dim;
     }
     smcmc_engine* h = new (std::nothrow) smcmc_engine();
     if (!h) return SMCMC_ERR_RUNTIME;

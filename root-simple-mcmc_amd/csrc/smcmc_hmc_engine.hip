@@ -48,6 +48,11 @@ struct smcmc_hmc {
     int fold_nslices = 0, slice_chains = 0;
     double *d_p0 = nullptr, *d_qprev = nullptr, *d_gacc = nullptr, *d_moments = nullptr, *d_zero = nullptr;
     double* h_moments = nullptr;   // pinned: the packed moments come back every sync
+    // PotentialGradient types 2 / 3 / 5 (TSimpleHMC.H:467-532): the GENERIC instantiation of hmc_step_kernel
+    int gradient_type = 0;
+    double *d_Eperm = nullptr;     // QUADFORM: Error in hmc_step_kernel's layout (d_E holds the matrix kernels')
+    double *d_covE = nullptr, *d_cov_avg = nullptr, *d_fd_grad = nullptr;
+    bool cov_dirty = true;         // fEstimatedError / fAveragePoint changed since the last upload
     std::string error;
 };
 
@@ -87,7 +92,9 @@ size_t hmc_gacc_doubles(const smcmc_hmc* h) {
 
 // the chains retune themselves (TSimpleHMC.H:302-345, 833-847) unless both the step length and the count are fixed
 bool hmc_adaptive(const smcmc_hmc* h) { return h->mean_epsilon > 0.0 || h->leapfrog > 0; }
-bool hmc_tracking(const smcmc_hmc* h) { return hmc_adaptive(h) || h->track_cov; }
+bool hmc_generic_gradient(const smcmc_hmc* h) { return h->gradient_type == 2 || h->gradient_type == 3 || h->gradient_type == 5; }
+// the covariant gradient reads the running covariance: it has to be kept
+bool hmc_tracking(const smcmc_hmc* h) { return hmc_adaptive(h) || h->track_cov || h->gradient_type == 2; }
 
 // What an UpdateErrorMatrix that went through does to every chain (TSimpleHMC.H:833-847)
 __global__ void hmc_retune_kernel(double* lane_f64, int32_t* lane_i32, int npad, int nchains, double max_scale,
@@ -130,7 +137,57 @@ HmcParams hmc_params(smcmc_hmc* h, int nsteps, int init_only) {
     p.q = h->d_q; p.pm = h->d_pm; p.qn = h->d_qn; p.pn = h->d_pn;
     p.lane_f64 = h->d_lane_f64; p.lane_i32 = h->d_lane_i32;
     p.p0 = h->d_p0; p.qprev = h->d_qprev;
+    p.gradient_type = h->gradient_type;
+    if (hmc_generic_gradient(h)) {
+        p.Eperm = h->d_Eperm;
+        p.cov_Eperm = h->d_covE; p.cov_average = h->d_cov_avg; p.fd_grad = h->d_fd_grad;
+    }
     return p;
+}
+
+// M [dim][dim] row-major -> hmc_step_kernel's layout: out[w][j][il] = M(il*W + w, j)
+std::vector<double> hmc_permute(const smcmc_hmc* h, const double* M) {
+    const int D = h->dim, W = h->W;
+    std::vector<double> perm((size_t)W * D * kPanelCW, 0.0);
+    for (int w = 0; w < W; ++w)
+        for (int j = 0; j < D; ++j)
+            for (int il = 0; il < kPanelCW; ++il) {
+                const int i = il * W + w;
+                if (i < D) perm[((size_t)w * D + j) * kPanelCW + il] = M[(size_t)i * D + j];
+            }
+    return perm;
+}
+
+// buffers of the GENERIC gradient types, allocated when one is first asked for; the estimated error matrix and the
+// average point go up again whenever the pooled update changed them
+int hmc_generic_buffers(smcmc_hmc* h) {
+    const int D = h->dim;
+    const size_t perm_bytes = sizeof(double) * (size_t)h->W * D * kPanelCW;
+    if (h->likelihood == SMCMC_LIKE_QUADFORM && !h->d_Eperm) {
+        HMC_TRY(h, hipMalloc(&h->d_Eperm, perm_bytes));
+        const std::vector<double> perm = hmc_permute(h, h->like_params.data());
+        HMC_TRY(h, hipMemcpyAsync(h->d_Eperm, perm.data(), perm_bytes, hipMemcpyHostToDevice, h->stream));
+        HMC_TRY(h, hipStreamSynchronize(h->stream));
+    }
+    if (h->gradient_type == 3 && !h->d_fd_grad) {
+        HMC_TRY(h, hipMalloc(&h->d_fd_grad, sizeof(double) * (size_t)h->npad * D));
+        HMC_TRY(h, hipMemsetAsync(h->d_fd_grad, 0, sizeof(double) * (size_t)h->npad * D, h->stream));
+    }
+    if (h->gradient_type == 2) {
+        if (!h->d_covE) {
+            HMC_TRY(h, hipMalloc(&h->d_covE, perm_bytes));
+            HMC_TRY(h, hipMalloc(&h->d_cov_avg, sizeof(double) * D));
+            h->cov_dirty = true;
+        }
+        if (h->cov_dirty) {
+            const std::vector<double> perm = hmc_permute(h, h->shared->error.data());
+            HMC_TRY(h, hipMemcpyAsync(h->d_covE, perm.data(), perm_bytes, hipMemcpyHostToDevice, h->stream));
+            HMC_TRY(h, hipMemcpyAsync(h->d_cov_avg, h->shared->average.data(), sizeof(double) * D, hipMemcpyHostToDevice, h->stream));
+            HMC_TRY(h, hipStreamSynchronize(h->stream));   // the staging vector goes out of scope
+            h->cov_dirty = false;
+        }
+    }
+    return SMCMC_OK;
 }
 
 template <typename T>
@@ -177,6 +234,7 @@ int hmc_sync(smcmc_hmc* h) {
     S.stepCount = (int)h->step_count;
     S.leapfrogZero = (h->leapfrog == 0);
     S.absorb(M, steps);
+    h->cov_dirty = true;
     if (S.updateErrorMatrix()) {
         const int threads = 256;
         hipLaunchKernelGGL(hmc_retune_kernel, dim3((h->nchains + threads - 1) / threads), dim3(threads), 0, h->stream,
@@ -189,8 +247,9 @@ int hmc_sync(smcmc_hmc* h) {
 }
 
 hipError_t hmc_dispatch(smcmc_hmc* h, const HmcParams& p) {
-    if (h->use_mfma) return launch_hmc_mfma(p, h->stream);
-    if (h->use_matrix_exact) return launch_hmc_matrix_exact(p, h->stream);
+    const bool generic = hmc_generic_gradient(h) && !p.init_only;
+    if (h->use_mfma && !generic) return launch_hmc_mfma(p, h->stream);
+    if (h->use_matrix_exact && !generic) return launch_hmc_matrix_exact(p, h->stream);
     return (h->W == 4) ? launch_hmc<4, kPanelCW>(p, h->likelihood, h->stream)
                        : launch_hmc<8, kPanelCW>(p, h->likelihood, h->stream);
 }
@@ -204,6 +263,8 @@ int smcmc_hmc_create(int dim, int nchains, int likelihood, uint64_t seed, uint32
     if (!out) return SMCMC_ERR_INVALID;
     *out = nullptr;
     if (dim < 1 || nchains < 1) return SMCMC_ERR_INVALID;
+    if (likelihood >= SMCMC_LIKE_ASYM && likelihood <= SMCMC_LIKE_CONSTRAINED)
+        return SMCMC_ERR_UNSUPPORTED;   // the stress likelihoods have no gradient (TSimpleHMC.H:85-89 needs one)
     if (likelihood < SMCMC_LIKE_ISO_GAUSS || likelihood > SMCMC_LIKE_ROSENBROCK) return SMCMC_ERR_INVALID;
     if (likelihood == SMCMC_LIKE_ROSENBROCK && dim < 2) return SMCMC_ERR_INVALID;
     if (dim > 8 * kPanelCW) return SMCMC_ERR_UNSUPPORTED;
@@ -249,7 +310,8 @@ int smcmc_hmc_destroy(smcmc_hmc* h) {
     (void)hipFree(h->d_q); (void)hipFree(h->d_pm); (void)hipFree(h->d_qn); (void)hipFree(h->d_pn);
     (void)hipFree(h->d_E); (void)hipFree(h->d_like); (void)hipFree(h->d_lane_f64); (void)hipFree(h->d_lane_i32);
     (void)hipFree(h->d_p0); (void)hipFree(h->d_qprev); (void)hipFree(h->d_gacc); (void)hipFree(h->d_moments);
-    (void)hipFree(h->d_zero);
+    (void)hipFree(h->d_zero); (void)hipFree(h->d_Eperm); (void)hipFree(h->d_covE); (void)hipFree(h->d_cov_avg);
+    (void)hipFree(h->d_fd_grad);
     (void)hipHostFree(h->h_moments);
     delete h->shared;
     delete h;
@@ -318,6 +380,17 @@ int smcmc_hmc_set_sync_interval(smcmc_hmc* h, int steps) {
     h->sync_every = steps;
     return SMCMC_OK;
 }
+// Step(save, gradientType) (TSimpleHMC.H:279, 467-532).  0, 1 and 4 are the likelihood's own gradient here (every
+// device likelihood has one); 2 the covariant approximation from the pooled running covariance (which is then kept
+// whatever the tuning); 3 finite differences of the potential; 5 zero.
+int smcmc_hmc_set_gradient_type(smcmc_hmc* h, int type) {
+    if (!h || type < 0 || type > 5) return SMCMC_ERR_INVALID;
+    if (!h->exact && (type == 2 || type == 3 || type == 5))
+        return hfail(h, SMCMC_ERR_UNSUPPORTED, "gradient types 2, 3 and 5 run in reference-order arithmetic only");
+    h->gradient_type = type;
+    return SMCMC_OK;
+}
+int smcmc_hmc_get_gradient_type(const smcmc_hmc* h) { return h ? h->gradient_type : -1; }
 int smcmc_hmc_set_track_covariance(smcmc_hmc* h, int on) {
     if (!h) return SMCMC_ERR_INVALID;
     h->track_cov = on != 0;
@@ -346,7 +419,7 @@ int smcmc_hmc_get_covariance(smcmc_hmc* h, double* out) {
 int smcmc_hmc_start(smcmc_hmc* h, const double* x0, int broadcast) {
     if (!h || !x0) return SMCMC_ERR_INVALID;
     HMC_ON_DEVICE(h);
-    const int D = h->dim, N = h->nchains, W = h->W;
+    const int D = h->dim, N = h->nchains;
     const size_t NP = (size_t)h->npad;
     if (h->likelihood == SMCMC_LIKE_QUADFORM) {
         if ((int)h->like_params.size() != D * D)
@@ -382,13 +455,11 @@ int smcmc_hmc_start(smcmc_hmc* h, const double* x0, int broadcast) {
             HMC_TRY(h, hipStreamSynchronize(h->stream));
         }
         // Eperm[w][j][il] = Error(il*W + w, j): the rows a wavefront owns, contiguous per source column j
-        std::vector<double> perm((size_t)W * D * kPanelCW, 0.0);
-        for (int w = 0; w < W; ++w)
-            for (int j = 0; j < D; ++j)
-                for (int il = 0; il < kPanelCW; ++il) {
-                    const int i = il * W + w;
-                    if (i < D) perm[((size_t)w * D + j) * kPanelCW + il] = h->like_params[(size_t)i * D + j];
-                }
+        const std::vector<double> perm = hmc_permute(h, h->like_params.data());
+        if (h->d_Eperm) {
+            HMC_TRY(h, hipMemcpyAsync(h->d_Eperm, perm.data(), perm.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+            HMC_TRY(h, hipStreamSynchronize(h->stream));
+        }
         if (!h->use_mfma && !h->use_matrix_exact) {
             HMC_TRY(h, hipMemcpyAsync(h->d_E, perm.data(), perm.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
             HMC_TRY(h, hipStreamSynchronize(h->stream));
@@ -427,6 +498,7 @@ int smcmc_hmc_start(smcmc_hmc* h, const double* x0, int broadcast) {
     std::vector<double> p0(D);
     for (int d = 0; d < D; ++d) p0[d] = x[(size_t)d * NP];
     h->shared->start(p0.data());
+    h->cov_dirty = true;
     h->steps_in_window = 0;
     if (h->d_gacc) HMC_TRY(h, hipMemsetAsync(h->d_gacc, 0, sizeof(double) * hmc_gacc_doubles(h), h->stream));
     h->started = true;
@@ -438,6 +510,11 @@ int smcmc_hmc_step(smcmc_hmc* h, int nsteps) {
     if (!h->started) return hfail(h, SMCMC_ERR_INVALID, "Must initialize starting point");   // :280-284
     if (nsteps <= 0) return SMCMC_OK;
     HMC_ON_DEVICE(h);
+    if (hmc_generic_gradient(h)) {
+        if (!h->exact) return hfail(h, SMCMC_ERR_UNSUPPORTED, "gradient types 2, 3 and 5 run in reference-order arithmetic only");
+        int gst = hmc_generic_buffers(h);
+        if (gst) return gst;
+    }
     if (!hmc_tracking(h)) {
         // fixed step length and leapfrog count: the chains share nothing, one launch runs all the steps
         HmcParams p = hmc_params(h, nsteps, 0);
@@ -449,6 +526,10 @@ int smcmc_hmc_step(smcmc_hmc* h, int nsteps) {
     int st = hmc_tracking_buffers(h);
     if (st) return st;
     for (int s = 0; s < nsteps; ++s) {
+        if (h->gradient_type == 2 && h->cov_dirty) {
+            st = hmc_generic_buffers(h);
+            if (st) return st;
+        }
         HmcParams p = hmc_params(h, 1, 0);
         p.adaptive = 1;
         hipError_t e = hmc_dispatch(h, p);

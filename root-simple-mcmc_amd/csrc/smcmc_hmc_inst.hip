@@ -10,7 +10,15 @@ namespace smcmc {
 
 template <int W, int CW, int LIKE>
 static hipError_t go_hmc(const HmcParams& p, hipStream_t s) {
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(hmc_step_kernel<W, CW, LIKE>), dim3(p.npad / kWave), dim3(W * kWave), 0, s, p);
+    // PotentialGradient types 2 / 3 / 5 (TSimpleHMC.H:467-532) live in the GENERIC instantiation
+    const bool generic = p.gradient_type == 2 || p.gradient_type == 3 || p.gradient_type == 5;
+    if (generic) {
+        if (p.gradient_type == 2 && (p.cov_Eperm == nullptr || p.cov_average == nullptr)) return hipErrorInvalidValue;
+        if (p.gradient_type == 3 && p.fd_grad == nullptr) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(hmc_step_kernel<W, CW, LIKE, true>), dim3(p.npad / kWave), dim3(W * kWave), 0, s, p);
+    } else {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(hmc_step_kernel<W, CW, LIKE, false>), dim3(p.npad / kWave), dim3(W * kWave), 0, s, p);
+    }
     return hipGetLastError();
 }
 

@@ -71,8 +71,12 @@ struct HmcParams {
     int nchains, npad, dim, nsteps, leapfrog, init_only;
     int adaptive;          // 1: step length and leapfrog count are per chain (lanes) and retuned every step
                            // (TSimpleHMC.H:302-323, 342-344); one step per launch, the pre-step point kept in qprev
-    int gradient_type;     // PotentialGradient's type (TSimpleHMC.H:467-532): 0 the likelihood's gradient, 2 the
-                           // covariant approximation (cov_error, cov_average), 5 zero
+    int gradient_type;     // PotentialGradient's type (TSimpleHMC.H:467-532), GENERIC instantiation only: 0 / 1 / 4 the
+                           // likelihood's gradient, 2 the covariant approximation (cov_Eperm, cov_average), 3 finite
+                           // differences of the potential (fd_grad), 5 zero
+    const double* cov_Eperm;     // type 2: fEstimatedError in the layout of Eperm
+    const double* cov_average;   // type 2: fAveragePoint [dim]
+    double* fd_grad;             // type 3: the gradient as wavefront 0 assembles it [dim][npad]
     double* p0;            // adaptive: the momentum LeapFrog started from (the reversal test, :633-638) [dim][npad]
     double* qprev;         // adaptive: fAccepted as UpdateCovariance sees it (:338)                     [dim][npad]
     uint32_t step0, chain_offset;
@@ -88,7 +92,7 @@ struct HmcParams {
     int32_t* lane_i32;     // NACCEPT, LAST_ACCEPT, TRIALS = step count
 };
 
-template <int W, int CW, int LIKE>
+template <int W, int CW, int LIKE, bool GENERIC = false>
 __global__ void __launch_bounds__(W * kWave) hmc_step_kernel(const HmcParams p) {
     __shared__ double rbuf[kPanelRows * kWave];                                   // q rows of the current panel
     __shared__ __attribute__((aligned(16))) double ulds[W * kPanelRows * CW];     // Error^T panels / gather panels
@@ -151,9 +155,53 @@ __global__ void __launch_bounds__(W * kWave) hmc_step_kernel(const HmcParams p) 
         __syncthreads();
     };
 
-    // potential gradient at qn for the owned components -> gr[]  (PotentialGradient type 0
+    // gr[il] = sum_j M(i, j) (qn_j - shift_j), j ascending, for the owned components i = il * W + w; Mperm in the layout
+    // of Eperm.  The sum is run as g = 0; g -= M q; g = -g, which rounds exactly like the ascending sum of the products.
+    auto contract = [&](const double* Mperm, const double* shift) {
+#pragma unroll
+        for (int il = 0; il < CW; ++il) gr[il] = 0.0;
+        for (int pnl = 0; pnl < npanels; ++pnl) {
+            const int j0 = pnl * kPanelRows;
+            const int j1 = (j0 + kPanelRows < D) ? j0 + kPanelRows : D;
+            __syncthreads();
+            for (int r = w; r < j1 - j0; r += W) {
+                double v = p.qn[(size_t)(j0 + r) * NP + chain];
+                if (shift != nullptr) v = v - shift[j0 + r];
+                rbuf[r * kWave + lane] = v;
+            }
+            {
+                const f64x2* src = (const f64x2*)(Mperm + ((size_t)w * D + j0) * CW);
+                f64x2* dst = (f64x2*)(ulds + w * (kPanelRows * CW));
+                const int npieces = (j1 - j0) * (CW / 2);
+                for (int k = lane; k < npieces; k += kWave) dst[k] = src[k];
+            }
+            __syncthreads();
+            lds_cptr_f64 up = (lds_cptr_f64)(ulds + w * (kPanelRows * CW));
+            asm volatile("" : "+v"(up));
+            for (int j = j0; j < j1; ++j) {
+                const double qj = rbuf[(j - j0) * kWave + lane];
+                lds_cptr_f64 erow = up + (j - j0) * CW;
+#pragma unroll
+                for (int c = 0; c < CW; c += 16) {
+                    f64x2 e2[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) e2[k] = *(volatile lds_cptr_f64x2)(erow + c + 2 * k);
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        gr[c + k] -= e2[k / 2][k & 1] * qj;
+                        asm volatile("" : "+v"(gr[c + k]));
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int il = 0; il < CW; ++il) gr[il] = -gr[il];
+        __syncthreads();
+    };
+
+    // the likelihood's own potential gradient at qn for the owned components -> gr[]  (PotentialGradient type 0
     // with the user gradient, TSimpleHMC.H:467-492: the negated gradient of log L)
-    auto gradient = [&]() {
+    auto like_gradient = [&]() {
         __syncthreads();   // every owner has written its part of qn
         if constexpr (LIKE == SMCMC_LIKE_ISO_GAUSS) {
 #pragma unroll
@@ -188,42 +236,8 @@ __global__ void __launch_bounds__(W * kWave) hmc_step_kernel(const HmcParams p) 
                 gr[il] = -g;       // TSimpleHMC.H:486
             }
         } else {
-            // TDummyLogLikelihood.H:34-42: g[i] = 0; g[i] -= Error(i,j)*p[j], j ascending
-#pragma unroll
-            for (int il = 0; il < CW; ++il) gr[il] = 0.0;
-            for (int pnl = 0; pnl < npanels; ++pnl) {
-                const int j0 = pnl * kPanelRows;
-                const int j1 = (j0 + kPanelRows < D) ? j0 + kPanelRows : D;
-                __syncthreads();
-                for (int r = w; r < j1 - j0; r += W) rbuf[r * kWave + lane] = p.qn[(size_t)(j0 + r) * NP + chain];
-                {
-                    const f64x2* src = (const f64x2*)(p.Eperm + ((size_t)w * D + j0) * CW);
-                    f64x2* dst = (f64x2*)(ulds + w * (kPanelRows * CW));
-                    const int npieces = (j1 - j0) * (CW / 2);
-                    for (int k = lane; k < npieces; k += kWave) dst[k] = src[k];
-                }
-                __syncthreads();
-                lds_cptr_f64 up = (lds_cptr_f64)(ulds + w * (kPanelRows * CW));
-                asm volatile("" : "+v"(up));
-                for (int j = j0; j < j1; ++j) {
-                    const double qj = rbuf[(j - j0) * kWave + lane];
-                    lds_cptr_f64 erow = up + (j - j0) * CW;
-#pragma unroll
-                    for (int c = 0; c < CW; c += 16) {
-                        f64x2 e2[8];
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) e2[k] = *(volatile lds_cptr_f64x2)(erow + c + 2 * k);
-#pragma unroll
-                        for (int k = 0; k < 16; ++k) {
-                            gr[c + k] -= e2[k / 2][k & 1] * qj;
-                            asm volatile("" : "+v"(gr[c + k]));
-                        }
-                    }
-                }
-            }
-#pragma unroll
-            for (int il = 0; il < CW; ++il) gr[il] = -gr[il];   // TSimpleHMC.H:486
-            __syncthreads();
+            // TDummyLogLikelihood.H:34-42: g[i] = 0; g[i] -= Error(i,j)*p[j], j ascending; then TSimpleHMC.H:486
+            contract(p.Eperm, nullptr);
         }
     };
 
@@ -252,7 +266,7 @@ __global__ void __launch_bounds__(W * kWave) hmc_step_kernel(const HmcParams p) 
             // log L = -1/2 q^T Error q.  The gradient at the final position is still in gr[]
             // (gr = Error q): the potential is folded from it in dimension order instead of
             // re-running the D^2-term sum of TDummyLogLikelihood.H:24-28 serially.
-            if (!gradient_is_current) gradient();
+            if (!gradient_is_current) like_gradient();
             double usum = 0.0;
             gather([&](int il, double& a, double& b) {
                        const int i = il * W + w;
@@ -264,6 +278,57 @@ __global__ void __launch_bounds__(W * kWave) hmc_step_kernel(const HmcParams p) 
         }
         return lsum;
     };
+
+    // PotentialGradient (:467-532) at qn -> gr[]
+    auto gradient = [&]() {
+        if constexpr (!GENERIC) {
+            like_gradient();
+        } else {
+            if (p.gradient_type == 2) {
+                // CovariantGradient (:447-454): grad[i] += fEstimatedError(i,j) * (point[j] - fAveragePoint[j])
+                __syncthreads();
+                contract(p.cov_Eperm, p.cov_average);
+            } else if (p.gradient_type == 3) {
+                // FiniteDifferenceGradient (:417-444): two potentials per dimension, du = 0.01.  Wavefront 0 moves
+                // the coordinate, receives the potentials and keeps the result in fd_grad.
+                const double du = 0.01;
+                for (int i = 0; i < D; ++i) {
+                    __syncthreads();
+                    double* cell = p.qn + (size_t)i * NP + chain;
+                    const double keep = (w == 0) ? *cell : 0.0;
+                    double work = keep;
+                    work -= du;
+                    if (w == 0) *cell = work;
+                    __syncthreads();
+                    double unused = 0.0;
+                    const double u1 = -log_likelihood_at_qn(false, unused);
+                    work += 2.0 * du;
+                    if (w == 0) *cell = work;
+                    __syncthreads();
+                    const double u2 = -log_likelihood_at_qn(false, unused);
+                    if (w == 0) {
+                        p.fd_grad[(size_t)i * NP + chain] = 0.5 * (u2 - u1) / du;
+                        *cell = keep;
+                    }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int il = 0; il < CW; ++il) {
+                    const int i = il * W + w;
+                    gr[il] = (i < D) ? p.fd_grad[(size_t)i * NP + chain] : 0.0;
+                }
+                __syncthreads();
+            } else if (p.gradient_type == 5) {
+                __syncthreads();
+#pragma unroll
+                for (int il = 0; il < CW; ++il) gr[il] = 0.0;
+            } else {
+                like_gradient();
+            }
+        }
+    };
+    // is gr[] the likelihood's own gradient after gradient()?  (the quadratic form folds its potential from it)
+    const bool own_gradient = !GENERIC || !(p.gradient_type == 2 || p.gradient_type == 3 || p.gradient_type == 5);
 
     if (p.init_only) {
         // Start (:210-269): SetPosition's Potential(start) for every chain
@@ -403,7 +468,7 @@ __global__ void __launch_bounds__(W * kWave) hmc_step_kernel(const HmcParams p) 
 
         // ---- proposed kinetic energy and potential (:326-327), dimension order ----
         double ke1 = 0.0;
-        const double lsum = log_likelihood_at_qn(Lmax >= 1, ke1);
+        const double lsum = log_likelihood_at_qn(Lmax >= 1 && own_gradient, ke1);
 
         // ---- Hamiltonian test (:333-387), wavefront 0 decides ----
         if (w == 0) {

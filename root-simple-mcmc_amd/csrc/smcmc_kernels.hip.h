@@ -235,6 +235,48 @@ __device__ __forceinline__ double loglike(const double (&p)[DP], cptr_f64 prm, i
 #ifdef SMCMC_USER_LIKELIHOOD
         logl = smcmc_user_loglike<DP>(p, prm, D);
 #endif
+    } else if constexpr (LIKE == SMCMC_LIKE_ASYM) {
+        // TAsymLogLikelihood.H:20-31 (the same arithmetic in both orders: there is nothing to fuse)
+        const double positive = prm[0], negative = prm[1];
+#pragma unroll
+        for (int i = 0; i < DP; ++i) {
+            if (i < D) {
+                double a = p[i];
+                a = (a < 0.0) ? a * negative : a * positive;
+                logl += a;
+            }
+        }
+    } else if constexpr (LIKE == SMCMC_LIKE_HORRIFIC) {
+        // THorrificLogLikelihood.H:26-38: -1E+30 as soon as a coordinate leaves the unit box
+        bool outside = false;
+#pragma unroll
+        for (int i = 0; i < DP; ++i) {
+            if (i < D) {
+                outside = outside || (__builtin_fabs(p[i]) > 1.0);
+                logl += p[i];
+            }
+        }
+        const double sigma = 0.01;
+        const double natural = __builtin_sqrt(D * 4.0 / 12.0);
+        logl /= natural;
+        logl = -0.5 * logl * logl / sigma / sigma;
+        logl = outside ? -1E+30 : logl;
+    } else if constexpr (LIKE == SMCMC_LIKE_CONSTRAINED) {
+        // example4/TConstrainedLikelihood.H:26-46; prm = {SummedValues, SummedConstraint, Expected[D], Prior[D]}
+        double sum = 0.0;
+#pragma unroll
+        for (int i = 0; i < DP; ++i)
+            if (i < D) sum += p[i];
+        sum = (sum - prm[0]) / prm[1];
+        logl -= 0.5 * sum * sum;
+#pragma unroll
+        for (int i = 0; i < DP; ++i) {
+            if (i < D) {
+                double v = p[i] - prm[2 + i];
+                v /= prm[2 + D + i];
+                logl -= 0.5 * v * v;
+            }
+        }
     } else {
         // THardLogLikelihood.H:60-64
         const double rb = prm[0];
@@ -741,6 +783,16 @@ inline hipError_t launch_step(const StepParams& p, int like, bool exact, bool fu
         case SMCMC_LIKE_ISO_GAUSS: return launch_step_like<DP, SMCMC_LIKE_ISO_GAUSS>(p, exact, fullu, moments, special, stream);
         case SMCMC_LIKE_QUADFORM: return launch_step_like<DP, SMCMC_LIKE_QUADFORM>(p, exact, fullu, moments, special, stream);
         case SMCMC_LIKE_ROSENBROCK: return launch_step_like<DP, SMCMC_LIKE_ROSENBROCK>(p, exact, fullu, moments, special, stream);
+        // the stress likelihoods are built for two register-array sizes only (kStressDP)
+        case SMCMC_LIKE_ASYM:
+            if constexpr (DP == 31 || DP == 63) return launch_step_like<DP, SMCMC_LIKE_ASYM>(p, exact, fullu, moments, special, stream);
+            else return hipErrorInvalidValue;
+        case SMCMC_LIKE_HORRIFIC:
+            if constexpr (DP == 31 || DP == 63) return launch_step_like<DP, SMCMC_LIKE_HORRIFIC>(p, exact, fullu, moments, special, stream);
+            else return hipErrorInvalidValue;
+        case SMCMC_LIKE_CONSTRAINED:
+            if constexpr (DP == 31 || DP == 63) return launch_step_like<DP, SMCMC_LIKE_CONSTRAINED>(p, exact, fullu, moments, special, stream);
+            else return hipErrorInvalidValue;
 #ifdef SMCMC_USER_LIKELIHOOD
         case SMCMC_LIKE_USER: return launch_step_like<DP, SMCMC_LIKE_USER>(p, exact, fullu, moments, special, stream);
 #endif

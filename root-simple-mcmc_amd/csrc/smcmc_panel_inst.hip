@@ -27,6 +27,11 @@ hipError_t launch_panel<SMCMC_PANEL_W, kPanelCW>(const PanelParams& p, int like,
         case SMCMC_LIKE_ROSENBROCK:
             return p.special ? go_panel<W, CW, SMCMC_LIKE_ROSENBROCK, true>(p, s)
                              : go_panel<W, CW, SMCMC_LIKE_ROSENBROCK, false>(p, s);
+        case SMCMC_LIKE_ASYM:
+            return p.special ? go_panel<W, CW, SMCMC_LIKE_ASYM, true>(p, s) : go_panel<W, CW, SMCMC_LIKE_ASYM, false>(p, s);
+        case SMCMC_LIKE_HORRIFIC:
+            return p.special ? go_panel<W, CW, SMCMC_LIKE_HORRIFIC, true>(p, s)
+                             : go_panel<W, CW, SMCMC_LIKE_HORRIFIC, false>(p, s);
         case SMCMC_LIKE_QUADFORM:
             if (p.scratch == nullptr) return hipErrorInvalidValue;
             return p.special ? go_panel<W, CW, SMCMC_LIKE_QUADFORM, true>(p, s)
@@ -62,6 +67,10 @@ hipError_t launch_start_loglike(const double* x, int nchains, size_t npad, int D
     } else if (like == SMCMC_LIKE_ROSENBROCK) {
         if (exact) hipLaunchKernelGGL(HIP_KERNEL_NAME(start_loglike_kernel<SMCMC_LIKE_ROSENBROCK, true>), grid, block, 0, s, x, nchains, npad, D, like_params, logl_out);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(start_loglike_kernel<SMCMC_LIKE_ROSENBROCK, false>), grid, block, 0, s, x, nchains, npad, D, like_params, logl_out);
+    } else if (like == SMCMC_LIKE_ASYM) {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(start_loglike_kernel<SMCMC_LIKE_ASYM, true>), grid, block, 0, s, x, nchains, npad, D, like_params, logl_out);
+    } else if (like == SMCMC_LIKE_HORRIFIC) {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(start_loglike_kernel<SMCMC_LIKE_HORRIFIC, true>), grid, block, 0, s, x, nchains, npad, D, like_params, logl_out);
     } else if (like == SMCMC_LIKE_QUADFORM && exact) {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(start_loglike_kernel<SMCMC_LIKE_QUADFORM, true>), dim3((nchains + 63) / 64), dim3(64), 0, s, x, nchains, npad, D, like_params, logl_out);
     } else {

@@ -339,6 +339,7 @@ __global__ void __launch_bounds__(W * kWave) panel_step_kernel(const PanelParams
 
         // ---- gather: wavefront 0 walks the proposal in dimension order ----
         double sqr = 0.0, lsum = 0.0, prev_p = 0.0;
+        bool outside = false;   // HORRIFIC: a coordinate left the unit box
         const double rb = (LIKE == SMCMC_LIKE_ROSENBROCK) ? likep[0] : 0.0;
         // xp[] must be indexed statically to stay in registers: the panel number selects one of
         // `ngather` fully unrolled write blocks; the (long) serial walk below is emitted once
@@ -374,6 +375,12 @@ __global__ void __launch_bounds__(W * kWave) panel_step_kernel(const PanelParams
                                 else lsum = SMCMC_FMA(t, pj, lsum);
                             } else if constexpr (LIKE == SMCMC_LIKE_QUADFORM) {
                                 (void)pj;   // summed below, from the global image
+                            } else if constexpr (LIKE == SMCMC_LIKE_ASYM) {
+                                const double a = (pj < 0.0) ? pj * likep[1] : pj * likep[0];   // TAsymLogLikelihood.H:24-28
+                                lsum += a;
+                            } else if constexpr (LIKE == SMCMC_LIKE_HORRIFIC) {
+                                outside = outside || (__builtin_fabs(pj) > 1.0);               // THorrificLogLikelihood.H:30-33
+                                lsum += pj;
                             } else {
                                 // term i = j-1 of THardLogLikelihood.H:60-64 needs p[j-1] and p[j]
                                 if (j > 0) {
@@ -457,6 +464,13 @@ __global__ void __launch_bounds__(W * kWave) panel_step_kernel(const PanelParams
                 }
                 if (summing) lsum = acc;
             }
+        }
+
+        if constexpr (LIKE == SMCMC_LIKE_HORRIFIC) {
+            const double sigma = 0.01;                                                         // :27, 34-37
+            lsum /= __builtin_sqrt(D * 4.0 / 12.0);
+            lsum = -0.5 * lsum * lsum / sigma / sigma;
+            lsum = outside ? -1E+30 : lsum;
         }
 
         // ---- wavefront 0: StepRMS, Metropolis test (TSimpleMCMC.H:397-463) ----
@@ -558,6 +572,22 @@ __global__ void start_loglike_kernel(const double* __restrict__ x, int nchains, 
     } else if constexpr (LIKE == SMCMC_LIKE_QUADFORM) {
         static_assert(EXACT || LIKE != SMCMC_LIKE_QUADFORM, "the fused order of the quadratic form is the matrix-pipe kernel's");
         lsum = quadform_serial(x + chain, npad, as_const(like), D);
+    } else if constexpr (LIKE == SMCMC_LIKE_ASYM) {
+        for (int i = 0; i < D; ++i) {
+            const double pi = x[(size_t)i * npad + chain];
+            lsum += (pi < 0.0) ? pi * like[1] : pi * like[0];
+        }
+    } else if constexpr (LIKE == SMCMC_LIKE_HORRIFIC) {
+        bool outside = false;
+        for (int i = 0; i < D; ++i) {
+            const double pi = x[(size_t)i * npad + chain];
+            outside = outside || (__builtin_fabs(pi) > 1.0);
+            lsum += pi;
+        }
+        const double sigma = 0.01;
+        lsum /= __builtin_sqrt(D * 4.0 / 12.0);
+        lsum = -0.5 * lsum * lsum / sigma / sigma;
+        lsum = outside ? -1E+30 : lsum;
     } else {
         const double rb = like[0];
         double prev = x[chain];

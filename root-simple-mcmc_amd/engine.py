@@ -10,7 +10,7 @@ import ctypes as C
 import numpy as np
 
 from . import _capi
-from ._capi import (LIKE_ISO_GAUSS, LIKE_QUADFORM, LIKE_ROSENBROCK, LIKE_USER, MODE_FROZEN, MODE_POOLED, P,  # noqa: F401
+from ._capi import (LIKE_ASYM, LIKE_CONSTRAINED, LIKE_HORRIFIC, LIKE_ISO_GAUSS, LIKE_QUADFORM, LIKE_ROSENBROCK, LIKE_USER, MODE_FROZEN, MODE_POOLED, P,  # noqa: F401
                     SmcmcError)
 
 _dp = C.POINTER(C.c_double)
@@ -481,6 +481,13 @@ class HmcEngine:
 
     def SetSyncInterval(self, steps): self._check(self._lib.smcmc_hmc_set_sync_interval(self._h, int(steps)))
     def TrackCovariance(self, on=True): self._check(self._lib.smcmc_hmc_set_track_covariance(self._h, int(on)))
+
+    def SetGradientType(self, gradient_type):
+        """Step(save, gradientType) of TSimpleHMC.H:279: 0 / 1 / 4 the likelihood's gradient, 2 covariant, 3 finite
+        differences, 5 zero (PotentialGradient, :467-532)."""
+        self._check(self._lib.smcmc_hmc_set_gradient_type(self._h, int(gradient_type)))
+
+    def GetGradientType(self): return int(self._lib.smcmc_hmc_get_gradient_type(self._h))
     def sync(self): self._check(self._lib.smcmc_hmc_sync(self._h))
 
     @property
@@ -512,7 +519,9 @@ class HmcEngine:
             raise ValueError("start must be [dim] or [dim][nchains]")
         self._check(self._lib.smcmc_hmc_start(self._h, _ptr(start), broadcast))
 
-    def Step(self, nsteps=1):
+    def Step(self, nsteps=1, gradient_type=None):
+        if gradient_type is not None:
+            self.SetGradientType(gradient_type)
         self._check(self._lib.smcmc_hmc_step(self._h, int(nsteps)))
 
     def state(self):

@@ -218,3 +218,69 @@ def test_hmc_config5_default_tuning_d500(gpu, oracle):
         e.Step(4); o.step(4)
         _same_hmc(e, o, f"exact={exact}")
         assert np.all(e.lane("leapfrog") > 0)
+
+
+# ---------------------------------------------------------------- Step(save, gradientType), TSimpleHMC.H:467-532
+@pytest.mark.parametrize("kind,dim,nchains", [(0, 5, 70), (2, 6, 64), (1, 12, 64), (0, 100, 64), (1, 100, 64), (2, 300, 64)])
+def test_hmc_covariant_gradient(gpu, oracle, kind, dim, nchains):
+    """Type 2: the gradient from the pooled running covariance, grad = fEstimatedError (q - fAveragePoint) (:447-454);
+    the potential stays the likelihood's."""
+    prm = [100.0] if kind == 2 else (np.linalg.inv(_spd(dim, 11)) if kind == 1 else None)
+    e, o = _adaptive_pair(gpu, oracle, dim, nchains, kind, prm, True, 2)
+    x0 = np.full(dim, 0.8)
+    e.Start(x0); o.start(x0)
+    e.SetGradientType(2); o.set_gradient_type(2)
+    assert e.GetGradientType() == 2
+    for k in range(3):
+        e.Step(5); o.step(5)
+        _same_hmc(e, o, f"block {k}")
+    assert e.lane("naccept").sum() > 0
+
+
+def test_hmc_covariant_gradient_with_a_fixed_step(gpu, oracle):
+    """The covariant gradient needs the running covariance: it is kept although nothing else asks for it."""
+    dim, n = 10, 64
+    e, o = _adaptive_pair(gpu, oracle, dim, n, 0, None, True, 1)
+    x0 = np.full(dim, 0.3)
+    e.Start(x0); o.start(x0)
+    e.SetMeanEpsilon(-0.1); o.set_mean_epsilon(-0.1)
+    e.SetLeapFrog(6); o.set_leapfrog(6)
+    e.Step(10, gradient_type=2); o.set_gradient_type(2); o.step(10)
+    _same_hmc(e, o, "fixed step, covariant gradient")
+    assert e.tuning["cov_trials"] > 0
+
+
+@pytest.mark.parametrize("kind,dim,nchains", [(0, 5, 70), (2, 6, 64), (1, 9, 64), (0, 70, 64)])
+def test_hmc_finite_difference_gradient(gpu, oracle, kind, dim, nchains):
+    """Type 3: two potentials per dimension, du = 0.01 (:417-444)."""
+    prm = [100.0] if kind == 2 else (np.linalg.inv(_spd(dim, 12)) if kind == 1 else None)
+    e, o = _adaptive_pair(gpu, oracle, dim, nchains, kind, prm, True, 1)
+    x0 = np.full(dim, 0.9)
+    e.Start(x0); o.start(x0)
+    e.SetGradientType(3); o.set_gradient_type(3)
+    for k in range(2):
+        e.Step(3); o.step(3)
+        _same_hmc(e, o, f"block {k}")
+
+
+@pytest.mark.parametrize("kind,dim", [(0, 5), (1, 20), (2, 100)])
+def test_hmc_zero_gradient_and_switching_types(gpu, oracle, kind, dim):
+    """Type 5 (free flight: the momentum never changes inside LeapFrog), then back to the likelihood's gradient (types
+    1 and 4 are type 0 here: every device likelihood has a gradient), the way Step(save, gradientType) allows."""
+    n = 64
+    prm = [100.0] if kind == 2 else (np.linalg.inv(_spd(dim, 13)) if kind == 1 else None)
+    e, o = _adaptive_pair(gpu, oracle, dim, n, kind, prm, True, 1)
+    x0 = np.full(dim, 0.7)
+    e.Start(x0); o.start(x0)
+    for t in (5, 0, 2, 4, 5, 1):
+        e.Step(3, gradient_type=t); o.set_gradient_type(t); o.step(3)
+        _same_hmc(e, o, f"after type {t}")
+
+
+def test_hmc_gradient_types_need_reference_order(gpu):
+    e = gpu.HmcEngine(8, 64, likelihood=0, exact=False)
+    with pytest.raises(gpu.SmcmcError) as err:
+        e.SetGradientType(2)
+    assert err.value.status == 5   # SMCMC_ERR_UNSUPPORTED
+    with pytest.raises(gpu.SmcmcError):
+        e.SetGradientType(6)

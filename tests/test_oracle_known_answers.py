@@ -67,6 +67,44 @@ def test_likelihood_functors(oracle):
     assert np.isclose(oracle.loglike(oracle.LIKE_QUADFORM, p), -0.5 * p @ err @ p, rtol=1e-9)
 
 
+def test_stress_likelihood_functors(oracle):
+    """TAsymLogLikelihood.H:20-31, THorrificLogLikelihood.H:26-38, example4/TConstrainedLikelihood.H:26-46 by hand."""
+    rng = np.random.default_rng(4)
+    p = rng.standard_normal(100)
+    want = float(np.sum(np.where(p < 0.0, 100.0 * p, -1.0 * p)))
+    assert np.isclose(oracle.loglike(oracle.LIKE_ASYM, p), want, rtol=1e-13)
+    assert oracle.loglike(oracle.LIKE_ASYM, np.zeros(100)) == 0.0                 # the maximum
+    q = rng.uniform(-1.0, 1.0, 75)
+    t = np.sum(q) / np.sqrt(75 * 4.0 / 12.0)
+    assert np.isclose(oracle.loglike(oracle.LIKE_HORRIFIC, q), -0.5 * t * t / 0.01 / 0.01, rtol=1e-13)
+    q[40] = 1.0000001
+    assert oracle.loglike(oracle.LIKE_HORRIFIC, q) == -1E+30
+    q[40] = -1.0                                                                  # the edge is inside (":30 > 1.0")
+    assert oracle.loglike(oracle.LIKE_HORRIFIC, q) > -1E+30
+    prm = oracle.constrained_params(25)
+    assert prm.size == 52 and prm[0] == 1902.0 and prm[1] == 16.0
+    assert np.all(prm[2:26] == 76.0) and prm[26] == 80.0 and np.all(prm[27:51] == 76.0 * 0.08) and prm[51] == 2.0
+    x = 76.0 + rng.standard_normal(25)
+    want = -0.5 * ((x.sum() - 1902.0) / 16.0) ** 2 - 0.5 * np.sum(((x - prm[2:27]) / prm[27:]) ** 2)
+    assert np.isclose(oracle.loglike(oracle.LIKE_CONSTRAINED, x, prm), want, rtol=1e-13)
+
+
+def test_stress_likelihoods_run_in_the_ensemble_oracle(oracle):
+    """Lane 0 of the frozen ensemble oracle is the single-chain oracle for the new kinds too (both orders share the
+    likelihood arithmetic; the proposal arithmetic differs)."""
+    for kind, dim in ((oracle.LIKE_ASYM, 12), (oracle.LIKE_HORRIFIC, 9), (oracle.LIKE_CONSTRAINED, 25)):
+        prm = oracle.like_params(kind, dim)
+        x0 = np.full(dim, 76.0) if kind == oracle.LIKE_CONSTRAINED else np.full(dim, 0.1)
+        c = oracle.Chain(dim, kind=kind, params=prm if prm.size else None, chain_id=0)
+        c.set_covariance_frozen(1)
+        e = oracle.Ensemble(3, dim, kind=kind, params=prm if prm.size else None, mode=oracle.MODE_FROZEN, exact=True)
+        assert c.start(x0) and e.start(x0)
+        c.run_quiet(150)
+        e.step(150)
+        assert np.array_equal(e.x[:, 0], c.accepted), kind
+        assert e.lane("logl")[0] == c.scalars["accepted_logl"]
+
+
 def test_dummy_likelihood_init_d100(oracle):
     # SURVEY.md section 2 probe: Error(0,0)=Error(99,99)~5e5, Error(0,99)~-5e5, rest identity
     cov, err = oracle.dummy_error_matrix(100)

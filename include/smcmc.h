@@ -294,6 +294,53 @@ int smcmc_hmc_read_state(smcmc_hmc* h, double* q, double* momentum, double* logl
 int smcmc_hmc_read_lane_f64(smcmc_hmc* h, int field, double* out);
 int smcmc_hmc_read_lane_i32(smcmc_hmc* h, int field, int32_t* out);
 
+/* ---- variable-at-a-time chains: TSimpleMCMC<L, TProposeVAATStep> ---------
+ * N independent chains of sMCMC::TSimpleMCMC<L, sMCMC::TProposeVAATStep> (TProposeVAATStep.H:22-307, the proposal
+ * SimpleVAAT.C drives): one coordinate per step from a shuffled queue of the dimensions (:52-78, 177-195), a proposal
+ * width per dimension adapted to a 44 % acceptance (:219-255).  Nothing is shared between chains; chain c is the
+ * reference chain on the random stream (seed, chain_offset + c).  Every likelihood id of smcmc_likelihood except USER;
+ * CONSTRAINED needs dim <= 63; dim <= 512.  The reference's quirks are kept: Start resets the acceptance window to 100
+ * the first time (:211), SetGaussian's sigma is the width of Gaus() unsquared (:69-78), RestoreState / AttachState /
+ * SaveState do nothing (:33-36). */
+typedef struct smcmc_vaat smcmc_vaat;
+int smcmc_vaat_create(int dim, int nchains, int likelihood, uint64_t seed, uint32_t chain_offset, int device,
+                      smcmc_vaat** out);
+int smcmc_vaat_destroy(smcmc_vaat* h);
+const char* smcmc_vaat_last_error(const smcmc_vaat* h);
+int smcmc_vaat_set_stream(smcmc_vaat* h, void* hip_stream);
+int smcmc_vaat_set_likelihood_params(smcmc_vaat* h, const double* params, int count);
+int smcmc_vaat_set_exact_arithmetic(smcmc_vaat* h, int exact);           /* 0: fused multiply-add order; before Start */
+int smcmc_vaat_set_uniform(smcmc_vaat* h, int dim, double minimum, double maximum);   /* SetUniform  :101 */
+int smcmc_vaat_set_gaussian(smcmc_vaat* h, int dim, double sigma);                    /* SetGaussian :123 */
+int smcmc_vaat_set_acceptance_window(smcmc_vaat* h, double a);           /* SetAcceptanceWindow :137 (an int member) */
+int smcmc_vaat_get_acceptance_window(const smcmc_vaat* h, double* a);
+int smcmc_vaat_set_acceptance_rigidity(smcmc_vaat* h, double r);         /* SetAcceptanceRigidity :148 */
+int smcmc_vaat_get_acceptance_rigidity(const smcmc_vaat* h, double* r);
+int smcmc_vaat_set_step_rms_window(smcmc_vaat* h, int window);           /* TSimpleMCMC::SetStepRMSWindow */
+int smcmc_vaat_start(smcmc_vaat* h, const double* x0, int broadcast);    /* TSimpleMCMC::Start + InitializeState :198 */
+int smcmc_vaat_update_proposal(smcmc_vaat* h);                           /* UpdateProposal :177 (SimpleVAAT.C:44) */
+int smcmc_vaat_step(smcmc_vaat* h, int nsteps);                          /* nsteps x TSimpleMCMC::Step(false) */
+/* as smcmc_step_save: the accepted point [slot][dim][npad] (and logL [slot][npad]) after every stride-th step */
+int smcmc_vaat_step_save(smcmc_vaat* h, int nsteps, int stride, double* save_x_device, double* save_logl_device);
+int smcmc_vaat_total_steps(const smcmc_vaat* h);
+int smcmc_vaat_queue_length(const smcmc_vaat* h);                        /* entries left in fNextIndex */
+int smcmc_vaat_nchains_padded(const smcmc_vaat* h);
+int smcmc_vaat_read_state(smcmc_vaat* h, double* x, double* logl);       /* GetAccepted, x[dim][nchains] */
+/* lanes: SMCMC_LANE_LOGL / LAST_VALUE / STEP_RMS / LOGL_PROPOSED; TRIALS / SUCCESSES / NACCEPT / STEP_RMS_TRIALS /
+ * LAST_ACCEPT and SMCMC_VAAT_LANE_LAST_INDEX (fLastIndex) */
+#define SMCMC_VAAT_LANE_LAST_INDEX SMCMC_LANE_NEXT_UPDATE
+#define SMCMC_VAAT_LANE_PROPOSED_VALUE SMCMC_LANE_LAST_X0   /* f64: fProposed[fLastIndex] of the latest step */
+int smcmc_vaat_read_lane_f64(smcmc_vaat* h, int field, double* out);
+int smcmc_vaat_read_lane_i32(smcmc_vaat* h, int field, int32_t* out);
+/* per-dimension state as [dim][nchains] */
+#define SMCMC_VAAT_DIM_SIGMA 0              /* f64 fSigma            :296 */
+#define SMCMC_VAAT_DIM_ACCEPTANCE 1         /* f64 fAcceptance       :287 */
+#define SMCMC_VAAT_DIM_ACCEPTANCE_TRIALS 2  /* i32 fAcceptanceTrials :290 */
+#define SMCMC_VAAT_DIM_QUEUE 3              /* i32 fNextIndex        :266 (slots >= queue length are stale) */
+int smcmc_vaat_read_dim_f64(smcmc_vaat* h, int field, double* out);
+int smcmc_vaat_read_dim_i32(smcmc_vaat* h, int field, int32_t* out);
+int smcmc_vaat_state_device_ptr(smcmc_vaat* h, double** x, double** logl);
+
 /* ---- self test (no engine needed) --------------------------------------- */
 /* Runs every function of include/smcmc_detmath.h on the device for n inputs so
  * tests can compare device and host bit for bit.  kind: 0 log, 1 exp,

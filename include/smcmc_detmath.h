@@ -89,6 +89,9 @@ SMCMC_HD smcmc_u32x4 smcmc_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2,
 #define SMCMC_STREAM_STEP  0u   /* proposal + Metropolis draws of Step()      */
 #define SMCMC_STREAM_START 1u   /* randomised start points (SimpleMCMC.C:147) */
 #define SMCMC_STREAM_HMC   2u   /* momentum / epsilon / accept draws of HMC   */
+#define SMCMC_STREAM_VAAT  3u   /* TProposeVAATStep chains: words 0,1 the normal pair of the step's Gaus (first normal
+                                 * used), word 2 its Uniform(a,b), word 3 the Metropolis uniform, words 4+i the i-th
+                                 * Uniform() of a queue shuffle made during that step (TProposeVAATStep.H:190-193) */
 
 SMCMC_HD smcmc_u32x4 smcmc_draw_block(uint64_t seed, uint32_t chain, uint64_t step,
                                       uint32_t block, uint32_t stream) {

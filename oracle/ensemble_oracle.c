@@ -147,43 +147,7 @@ void oracle_ensemble_set_sigma(oracle_ensemble* e, double s) {
 }
 
 static double ens_like(const oracle_ensemble* e, const double* p) {
-    const int n = e->dim;
-    /* the stress likelihoods (asymmetric, horrific, constrained) have no fused form: the same arithmetic in both orders */
-    if (e->exact || e->like_kind >= ORACLE_LIKE_ASYM) return oracle_like(e->like_kind, n, p, e->like_params);
-    /* fused order (the "fast" arithmetic of the HIP kernels) */
-    double logl = 0.0;
-    switch (e->like_kind) {
-        case ORACLE_LIKE_ISO:
-            for (int i = 0; i < n; ++i) logl = SMCMC_FMA(-0.5 * p[i], p[i], logl);
-            return logl;
-        case ORACLE_LIKE_QUADFORM:
-            if (e->quadform_rowwise) {
-                /* the matrix-pipe kernel's association (smcmc_panel_mfma_kernel.hip.h): row sums of
-                 * Error p by fused multiply-adds, j ascending, then the outer sum in dimension order */
-                double usum = 0.0;
-                for (int i = 0; i < n; ++i) {
-                    double s = 0.0;
-                    for (int j = 0; j < n; ++j) s = SMCMC_FMA(e->like_params[i * n + j], p[j], s);
-                    usum += 0.5 * p[i] * s;
-                }
-                return -usum;
-            }
-            for (int i = 0; i < n; ++i) {
-                double h = 0.5 * p[i];
-                for (int j = 0; j < n; ++j) logl = SMCMC_FMA(-(h * e->like_params[j * n + i]), p[j], logl);
-            }
-            return logl;
-        default: {
-            double rb = e->like_params ? e->like_params[0] : 100.0;
-            for (int i = 0; i < n - 1; ++i) {
-                double a = 1.0 - p[i];
-                double b = SMCMC_FMA(-p[i], p[i], p[i + 1]);
-                double t = SMCMC_FMA(rb * b, b, a * a);
-                logl -= t;
-            }
-            return logl;
-        }
-    }
+    return oracle_like_order(e->like_kind, e->dim, p, e->like_params, e->exact, e->quadform_rowwise);
 }
 
 /* x0: [d][chain] when broadcast == 0, [d] when broadcast != 0.  Returns 0 if

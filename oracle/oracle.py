@@ -25,7 +25,7 @@ _bp = C.POINTER(C.c_uint8)
 def build(force=False):
     """Compile the oracle with the committed Makefile (gcc, a second or two)."""
     srcs = [os.path.join(_HERE, f) for f in
-            ("smcmc_oracle.c", "ensemble_oracle.c", "hmc_oracle.c", "oracle_core.h", "oracle_linalg.h")]
+            ("smcmc_oracle.c", "ensemble_oracle.c", "hmc_oracle.c", "vaat_oracle.c", "oracle_core.h", "oracle_linalg.h")]
     srcs.append(os.path.join(_HERE, "..", "include", "smcmc_detmath.h"))
     stale = force or not os.path.exists(_LIB_PATH) or any(
         os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs if os.path.exists(s))
@@ -119,6 +119,24 @@ def _declare(L):
         f.argtypes = [C.c_void_p] + args
     L.oracle_ensemble_start.restype = C.c_int
     L.oracle_ensemble_start.argtypes = [C.c_void_p, _dp, C.c_int]
+
+    L.oracle_vaat_create.restype = C.c_void_p
+    L.oracle_vaat_create.argtypes = [C.c_int, C.c_int, C.c_int, _dp, C.c_int, C.c_uint64, C.c_uint32, C.c_int]
+    L.oracle_vaat_destroy.argtypes = [C.c_void_p]
+    for name, args in [
+        ("set_gaussian", [C.c_int, C.c_double]), ("set_uniform", [C.c_int, C.c_double, C.c_double]),
+        ("set_acceptance_window", [C.c_double]), ("set_acceptance_rigidity", [C.c_double]),
+        ("set_step_rms_window", [C.c_int]), ("update_proposal", []), ("step", [C.c_int]), ("get_x", [_dp]),
+        ("get_lane_f64", [C.c_int, _dp]), ("get_lane_i32", [C.c_int, _ip]), ("get_dim_f64", [C.c_int, _dp]),
+        ("get_dim_i32", [C.c_int, _ip]),
+    ]:
+        f = getattr(L, "oracle_vaat_" + name)
+        f.restype = None
+        f.argtypes = [C.c_void_p] + args
+    L.oracle_vaat_start.restype = C.c_int
+    L.oracle_vaat_start.argtypes = [C.c_void_p, _dp, C.c_int]
+    L.oracle_vaat_get_acceptance_window.restype = C.c_int
+    L.oracle_vaat_get_acceptance_window.argtypes = [C.c_void_p]
 
     L.oracle_hmc_create.restype = C.c_void_p
     L.oracle_hmc_create.argtypes = [C.c_int, C.c_int, _dp, C.c_int, C.c_uint64, C.c_uint32]
@@ -549,6 +567,71 @@ class HmcEnsemble:
     @property
     def shared(self):
         return dict(zip(HMC_SHARED, self._vec("shared", len(HMC_SHARED))))
+
+
+class Vaat:
+    """N independent sMCMC::TSimpleMCMC<L, sMCMC::TProposeVAATStep> chains (oracle/vaat_oracle.c): chain c is the
+    reference chain on the random stream (seed, chain_offset + c)."""
+
+    LANE_F64 = {"logl": 0, "logl_proposed": 1, "step_rms": 2, "proposed_value": 3}
+    LANE_I32 = {"trials": 0, "successes": 1, "last_index": 2, "queue_len": 3, "naccept": 4, "last_accept": 5,
+                "step_rms_trials": 6}
+    DIM_F64 = {"sigma": 0, "acceptance": 1}
+    DIM_I32 = {"acceptance_trials": 0, "queue": 1}
+
+    def __init__(self, nchains, dim, kind=LIKE_ISO, params=None, seed=20240607, chain_offset=0, exact=True):
+        self.nchains, self.dim = nchains, dim
+        prm = like_params(kind, dim, params)
+        self._h = lib().oracle_vaat_create(nchains, dim, kind, _p(prm) if prm.size else None, prm.size, seed,
+                                           chain_offset, int(exact))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().oracle_vaat_destroy(self._h)
+            self._h = None
+
+    def __getattr__(self, name):
+        if name.startswith("set_") or name == "update_proposal":
+            f = getattr(lib(), "oracle_vaat_" + name)
+            return lambda *a: f(self._h, *a)
+        raise AttributeError(name)
+
+    def start(self, x0):
+        x0 = _f64(x0)
+        broadcast = int(x0.ndim == 1)
+        if not broadcast:
+            assert x0.shape == (self.dim, self.nchains)
+        return bool(lib().oracle_vaat_start(self._h, _p(x0), broadcast))
+
+    def step(self, nsteps=1): lib().oracle_vaat_step(self._h, nsteps)
+
+    @property
+    def x(self):
+        out = np.zeros((self.dim, self.nchains))
+        lib().oracle_vaat_get_x(self._h, _p(out))
+        return out
+
+    @property
+    def acceptance_window(self): return lib().oracle_vaat_get_acceptance_window(self._h)
+
+    def lane(self, name):
+        if name in self.LANE_F64:
+            out = np.zeros(self.nchains)
+            lib().oracle_vaat_get_lane_f64(self._h, self.LANE_F64[name], _p(out))
+            return out
+        out = np.zeros(self.nchains, np.int32)
+        lib().oracle_vaat_get_lane_i32(self._h, self.LANE_I32[name], out.ctypes.data_as(_ip))
+        return out
+
+    def per_dim(self, name):
+        """fSigma / fAcceptance / fAcceptanceTrials / fNextIndex as [dim][chain]."""
+        if name in self.DIM_F64:
+            out = np.zeros((self.dim, self.nchains))
+            lib().oracle_vaat_get_dim_f64(self._h, self.DIM_F64[name], _p(out))
+            return out
+        out = np.zeros((self.dim, self.nchains), np.int32)
+        lib().oracle_vaat_get_dim_i32(self._h, self.DIM_I32[name], out.ctypes.data_as(_ip))
+        return out
 
 
 def hmc_gradient(kind, p, params=None):

@@ -117,6 +117,46 @@ static double oracle_like(int kind, int dim, const double* p, const double* para
     }
 }
 
+/* The likelihood in one of the engine's two arithmetic orders: exact = the reference's operation order (oracle_like),
+ * otherwise the fused multiply-add order of the HIP kernels' "fast" arithmetic. */
+static double oracle_like_order(int kind, int n, const double* p, const double* params, int exact, int quadform_rowwise) {
+    /* the stress likelihoods (asymmetric, horrific, constrained) have no fused form: the same arithmetic in both orders */
+    if (exact || kind >= ORACLE_LIKE_ASYM) return oracle_like(kind, n, p, params);
+    double logl = 0.0;
+    switch (kind) {
+        case ORACLE_LIKE_ISO:
+            for (int i = 0; i < n; ++i) logl = SMCMC_FMA(-0.5 * p[i], p[i], logl);
+            return logl;
+        case ORACLE_LIKE_QUADFORM:
+            if (quadform_rowwise) {
+                /* the matrix-pipe kernel's association (smcmc_panel_mfma_kernel.hip.h): row sums of
+                 * Error p by fused multiply-adds, j ascending, then the outer sum in dimension order */
+                double usum = 0.0;
+                for (int i = 0; i < n; ++i) {
+                    double s = 0.0;
+                    for (int j = 0; j < n; ++j) s = SMCMC_FMA(params[i * n + j], p[j], s);
+                    usum += 0.5 * p[i] * s;
+                }
+                return -usum;
+            }
+            for (int i = 0; i < n; ++i) {
+                double h = 0.5 * p[i];
+                for (int j = 0; j < n; ++j) logl = SMCMC_FMA(-(h * params[j * n + i]), p[j], logl);
+            }
+            return logl;
+        default: {
+            double rb = params ? params[0] : 100.0;
+            for (int i = 0; i < n - 1; ++i) {
+                double a = 1.0 - p[i];
+                double b = SMCMC_FMA(-p[i], p[i], p[i + 1]);
+                double t = SMCMC_FMA(rb * b, b, a * a);
+                logl -= t;
+            }
+            return logl;
+        }
+    }
+}
+
 /* ---- the random stream standing in for gRandom --------------------------- */
 typedef struct {
     uint64_t seed;
@@ -125,12 +165,13 @@ typedef struct {
     uint32_t cached_block;
     int has_block;
     smcmc_u32x4 block;
+    uint32_t stream_id;  /* SMCMC_STREAM_STEP (0) unless a restatement says otherwise */
 } oracle_stream;
 
 static uint32_t oracle_stream_word(oracle_stream* s, uint32_t w) {
     uint32_t b = w >> 2;
     if (!s->has_block || s->cached_block != b) {
-        s->block = smcmc_draw_block(s->seed, s->chain, s->step, b, SMCMC_STREAM_STEP);
+        s->block = smcmc_draw_block(s->seed, s->chain, s->step, b, s->stream_id);
         s->cached_block = b;
         s->has_block = 1;
     }

@@ -9,7 +9,7 @@ a hyphen, so import it through the loader at the repo root:
 """
 from ._capi import (LIKE_ASYM, LIKE_CONSTRAINED, LIKE_HORRIFIC, LIKE_ISO_GAUSS, LIKE_QUADFORM, LIKE_ROSENBROCK, LIKE_USER, MODE_FROZEN, MODE_POOLED, SmcmcError,  # noqa: F401
                     LIB_PATH, SIGNATURES, load)
-from .engine import Autocorrelation, Engine, HmcEngine, PosteriorMoments, selftest_detmath, selftest_mfma, selftest_mfma_strip  # noqa: F401
+from .engine import Autocorrelation, Engine, HmcEngine, PosteriorMoments, VaatEngine, selftest_detmath, selftest_mfma, selftest_mfma_strip  # noqa: F401
 from . import build as _build_mod  # noqa: F401
 from . import distributed  # noqa: F401
 

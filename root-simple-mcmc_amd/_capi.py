@@ -29,6 +29,11 @@ LANE_I32 = {name: i for i, name in enumerate(
 # the HMC engine's aliases (SMCMC_HMC_LANE_* of include/smcmc.h)
 HMC_LANE_F64 = dict(LANE_F64, mean_epsilon=LANE_F64["sigma"], reversal_len=LANE_F64["rigidity"])
 HMC_LANE_I32 = dict(LANE_I32, leapfrog=LANE_I32["next_update"], contributes=LANE_I32["successes"])
+# the variable-at-a-time engine (SMCMC_VAAT_* of include/smcmc.h)
+VAAT_LANE_I32 = dict(LANE_I32, last_index=LANE_I32["next_update"])
+VAAT_LANE_F64 = dict(LANE_F64, proposed_value=LANE_F64["last_x0"])
+VAAT_DIM_F64 = {"sigma": 0, "acceptance": 1}
+VAAT_DIM_I32 = {"acceptance_trials": 2, "queue": 3}
 HMC_TUNING = ["trace", "orbit", "updates", "cov_trials", "average_trials", "steps_remaining", "steps_since_update",
               "max_scale", "min_scale", "est_trace"]
 
@@ -119,6 +124,32 @@ SIGNATURES = {
     "smcmc_hmc_read_state": (C.c_int, [_H, _dp, _dp, _dp]),
     "smcmc_hmc_read_lane_f64": (C.c_int, [_H, C.c_int, _dp]),
     "smcmc_hmc_read_lane_i32": (C.c_int, [_H, C.c_int, _ip]),
+    "smcmc_vaat_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint32, C.c_int, C.POINTER(_H)]),
+    "smcmc_vaat_destroy": (C.c_int, [_H]),
+    "smcmc_vaat_last_error": (C.c_char_p, [_H]),
+    "smcmc_vaat_set_stream": (C.c_int, [_H, C.c_void_p]),
+    "smcmc_vaat_set_likelihood_params": (C.c_int, [_H, _dp, C.c_int]),
+    "smcmc_vaat_set_exact_arithmetic": (C.c_int, [_H, C.c_int]),
+    "smcmc_vaat_set_uniform": (C.c_int, [_H, C.c_int, C.c_double, C.c_double]),
+    "smcmc_vaat_set_gaussian": (C.c_int, [_H, C.c_int, C.c_double]),
+    "smcmc_vaat_set_acceptance_window": (C.c_int, [_H, C.c_double]),
+    "smcmc_vaat_get_acceptance_window": (C.c_int, [_H, _dp]),
+    "smcmc_vaat_set_acceptance_rigidity": (C.c_int, [_H, C.c_double]),
+    "smcmc_vaat_get_acceptance_rigidity": (C.c_int, [_H, _dp]),
+    "smcmc_vaat_set_step_rms_window": (C.c_int, [_H, C.c_int]),
+    "smcmc_vaat_start": (C.c_int, [_H, _dp, C.c_int]),
+    "smcmc_vaat_update_proposal": (C.c_int, [_H]),
+    "smcmc_vaat_step": (C.c_int, [_H, C.c_int]),
+    "smcmc_vaat_step_save": (C.c_int, [_H, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "smcmc_vaat_total_steps": (C.c_int, [_H]),
+    "smcmc_vaat_queue_length": (C.c_int, [_H]),
+    "smcmc_vaat_nchains_padded": (C.c_int, [_H]),
+    "smcmc_vaat_read_state": (C.c_int, [_H, _dp, _dp]),
+    "smcmc_vaat_read_lane_f64": (C.c_int, [_H, C.c_int, _dp]),
+    "smcmc_vaat_read_lane_i32": (C.c_int, [_H, C.c_int, _ip]),
+    "smcmc_vaat_read_dim_f64": (C.c_int, [_H, C.c_int, _dp]),
+    "smcmc_vaat_read_dim_i32": (C.c_int, [_H, C.c_int, _ip]),
+    "smcmc_vaat_state_device_ptr": (C.c_int, [_H, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "smcmc_selftest_detmath": (C.c_int, [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp]),
     "smcmc_selftest_mfma": (C.c_int, [C.c_int, C.c_int, _dp, _dp, _dp]),
     "smcmc_selftest_mfma_strip": (C.c_int, [C.c_int, C.c_int, _dp, _dp, _dp]),

@@ -2,6 +2,7 @@
 // (register-array size, likelihood) pair; built once per
 // -DSMCMC_DP=<n> -DSMCMC_LIKE=<k> (see root-simple-mcmc_amd/build.py).
 #include "smcmc_kernels.hip.h"
+#include "smcmc_vaat_kernel.hip.h"
 
 #if !defined(SMCMC_DP) || !defined(SMCMC_LIKE)
 #error "compile with -DSMCMC_DP=<padded dimension> -DSMCMC_LIKE=<likelihood id>"
@@ -30,6 +31,17 @@ hipError_t launch_step_like<SMCMC_DP, SMCMC_LIKE>(const StepParams& p, bool exac
     if (exact) return mom ? go<DP, LIKE, true, false, true, false>(p, s) : go<DP, LIKE, true, false, false, false>(p, s);
     return mom ? go<DP, LIKE, false, false, true, false>(p, s) : go<DP, LIKE, false, false, false, false>(p, s);
 }
+
+#if SMCMC_LIKE != 3   // SMCMC_LIKE_USER (an enumerator, invisible to the preprocessor)
+// the variable-at-a-time chains on the same likelihood code (smcmc_vaat_kernel.hip.h)
+template <>
+hipError_t launch_vaat_like<SMCMC_DP, SMCMC_LIKE>(const VaatParams& p, bool exact, hipStream_t s) {
+    constexpr int DP = SMCMC_DP, LIKE = SMCMC_LIKE;
+    if (exact) hipLaunchKernelGGL(HIP_KERNEL_NAME(vaat_step_kernel<DP, LIKE, true>), dim3(p.npad / kWave), dim3(kWave), 0, s, p);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(vaat_step_kernel<DP, LIKE, false>), dim3(p.npad / kWave), dim3(kWave), 0, s, p);
+    return hipGetLastError();
+}
+#endif
 
 #if SMCMC_LIKE == 0
 template <>

@@ -81,7 +81,7 @@ __device__ __forceinline__ size_t step_pitch(size_t np) {
 // independent multiplies and one dependent subtraction, the memory latency of a group is hidden behind the previous one.
 constexpr int kQfGroup = 32;
 constexpr int kQfLds = 16;   // terms per group of the LDS-fed sum of the step kernel
-template <typename PointPtr>
+template <bool EXACT = true, typename PointPtr>
 __device__ __forceinline__ double quadform_serial(PointPtr pc, size_t NP, cptr_f64 et, int D) {
     double logl = 0.0;
     const int ngroups = D / kQfGroup;
@@ -101,12 +101,18 @@ __device__ __forceinline__ double quadform_serial(PointPtr pc, size_t NP, cptr_f
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int u = 0; u < kQfGroup; ++u) logl -= h * erow[j0 + u] * cur[u];
+            for (int u = 0; u < kQfGroup; ++u) {
+                if constexpr (EXACT) logl -= h * erow[j0 + u] * cur[u];
+                else logl = SMCMC_FMA(-(h * erow[j0 + u]), cur[u], logl);   // the fused order of loglike<DP, QUADFORM, false>
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int u = 0; u < kQfGroup; ++u) cur[u] = nxt[u];
         }
-        for (int j = ngroups * kQfGroup; j < D; ++j) logl -= h * erow[j] * pc[(size_t)j * NP];
+        for (int j = ngroups * kQfGroup; j < D; ++j) {
+            if constexpr (EXACT) logl -= h * erow[j] * pc[(size_t)j * NP];
+            else logl = SMCMC_FMA(-(h * erow[j]), pc[(size_t)j * NP], logl);
+        }
     }
     return logl;
 }
@@ -554,13 +560,11 @@ __global__ void __launch_bounds__(W * kWave) panel_step_kernel(const PanelParams
     }
 }
 
-// Start's likelihood call (TSimpleMCMC.H:258) for the large-dimension path: one thread
-// per chain walks its column of x in the reference's summation order.
+// log L of one chain's column of x ([dim][npad]) in the reference's summation order (EXACT) or the fused order of
+// loglike<DP, LIKE, false>; QUADFORM reads Error^T as a plain [D][D] matrix.
 template <int LIKE, bool EXACT>
-__global__ void start_loglike_kernel(const double* __restrict__ x, int nchains, size_t npad, int D,
-                                     const double* __restrict__ like, double* __restrict__ logl_out) {
-    const int chain = blockIdx.x * blockDim.x + threadIdx.x;
-    if (chain >= nchains) return;
+__device__ __forceinline__ double serial_loglike(const double* __restrict__ x, int chain, size_t npad, int D,
+                                                 const double* __restrict__ like) {
     double lsum = 0.0;
     if constexpr (LIKE == SMCMC_LIKE_ISO_GAUSS) {
         for (int i = 0; i < D; ++i) {
@@ -570,8 +574,7 @@ __global__ void start_loglike_kernel(const double* __restrict__ x, int nchains, 
             else lsum = SMCMC_FMA(t, pi, lsum);
         }
     } else if constexpr (LIKE == SMCMC_LIKE_QUADFORM) {
-        static_assert(EXACT || LIKE != SMCMC_LIKE_QUADFORM, "the fused order of the quadratic form is the matrix-pipe kernel's");
-        lsum = quadform_serial(x + chain, npad, as_const(like), D);
+        lsum = quadform_serial<EXACT>(x + chain, npad, as_const(like), D);
     } else if constexpr (LIKE == SMCMC_LIKE_ASYM) {
         for (int i = 0; i < D; ++i) {
             const double pi = x[(size_t)i * npad + chain];
@@ -606,7 +609,18 @@ __global__ void start_loglike_kernel(const double* __restrict__ x, int nchains, 
             prev = nx;
         }
     }
-    logl_out[chain] = lsum;
+    return lsum;
+}
+
+// Start's likelihood call (TSimpleMCMC.H:258) for the large-dimension path: one thread
+// per chain walks its column of x in the reference's summation order.
+template <int LIKE, bool EXACT>
+__global__ void start_loglike_kernel(const double* __restrict__ x, int nchains, size_t npad, int D,
+                                     const double* __restrict__ like, double* __restrict__ logl_out) {
+    const int chain = blockIdx.x * blockDim.x + threadIdx.x;
+    if (chain >= nchains) return;
+    static_assert(EXACT || LIKE != SMCMC_LIKE_QUADFORM, "the fused order of the quadratic form is the matrix-pipe kernel's");
+    logl_out[chain] = serial_loglike<LIKE, EXACT>(x, chain, npad, D, like);
 }
 
 template <int W, int CW>

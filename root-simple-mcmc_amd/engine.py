@@ -540,3 +540,134 @@ class HmcEngine:
         self._check(self._lib.smcmc_hmc_read_lane_i32(self._h, _capi.HMC_LANE_I32[name],
                                                       out.ctypes.data_as(C.POINTER(C.c_int32))))
         return out
+
+
+class VaatEngine:
+    """N independent sMCMC::TSimpleMCMC<L, sMCMC::TProposeVAATStep> chains (reference TProposeVAATStep.H:22-307 driven
+    by TSimpleMCMC::Step): one coordinate per step from a shuffled queue of the dimensions, a proposal width per
+    dimension adapted to a 44 % acceptance.  Chain c is the reference chain on the random stream (seed, chain_offset + c)."""
+
+    def __init__(self, dim, nchains=1, likelihood=LIKE_ISO_GAUSS, likelihood_params=None, seed=20240607,
+                 chain_offset=0, device=0, stream=None, exact=True):
+        self._lib = _capi.load()
+        self.dim, self.nchains = int(dim), int(nchains)
+        h = C.c_void_p()
+        st = self._lib.smcmc_vaat_create(self.dim, self.nchains, likelihood, seed, chain_offset, device, C.byref(h))
+        self._h = h
+        if st != _capi.OK:
+            msg = self._lib.smcmc_vaat_last_error(h).decode() if h else self._lib.smcmc_status_string(st).decode()
+            if h:
+                self._lib.smcmc_vaat_destroy(h)
+            self._h = None
+            raise SmcmcError(st, msg)
+        if likelihood_params is not None:
+            prm = _f64(likelihood_params).ravel()
+            self._check(self._lib.smcmc_vaat_set_likelihood_params(self._h, _ptr(prm), prm.size))
+        if stream is not None:
+            self._check(self._lib.smcmc_vaat_set_stream(self._h, C.c_void_p(int(stream))))
+        if not exact:
+            self._check(self._lib.smcmc_vaat_set_exact_arithmetic(self._h, 0))
+
+    def _check(self, st):
+        if st != _capi.OK:
+            raise SmcmcError(st, self._lib.smcmc_vaat_last_error(self._h).decode()
+                             or self._lib.smcmc_status_string(st).decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.smcmc_vaat_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- TProposeVAATStep's interface (GetProposeStep() of the reference) ----
+    def SetUniform(self, dim, minimum, maximum):
+        self._check(self._lib.smcmc_vaat_set_uniform(self._h, int(dim), float(minimum), float(maximum)))
+
+    def SetGaussian(self, dim, sigma): self._check(self._lib.smcmc_vaat_set_gaussian(self._h, int(dim), float(sigma)))
+    def SetAcceptanceWindow(self, a): self._check(self._lib.smcmc_vaat_set_acceptance_window(self._h, float(a)))
+    def SetAcceptanceRigidity(self, r): self._check(self._lib.smcmc_vaat_set_acceptance_rigidity(self._h, float(r)))
+    def SetStepRMSWindow(self, n): self._check(self._lib.smcmc_vaat_set_step_rms_window(self._h, int(n)))
+    def UpdateProposal(self): self._check(self._lib.smcmc_vaat_update_proposal(self._h))
+
+    def GetAcceptanceWindow(self):
+        out = C.c_double(0)
+        self._check(self._lib.smcmc_vaat_get_acceptance_window(self._h, C.byref(out)))
+        return out.value
+
+    def GetAcceptanceRigidity(self):
+        out = C.c_double(0)
+        self._check(self._lib.smcmc_vaat_get_acceptance_rigidity(self._h, C.byref(out)))
+        return out.value
+
+    def GetSuccesses(self, chain=0): return int(self.lane("successes")[chain])      # :151
+    def GetTrials(self, chain=0): return int(self.lane("trials")[chain])            # :154
+    def GetAcceptance(self, chain=0):                                               # :157-165: the mean over the dimensions
+        a = self.per_dim("acceptance")[:, chain]
+        return float(np.add.reduce(a) / a.size) if a.size else 0.0
+
+    def GetSigma(self, chain=0):                                                    # :168-175
+        s = self.per_dim("sigma")[:, chain]
+        return float(np.add.reduce(s) / s.size) if s.size else 0.0
+
+    # ---- TSimpleMCMC's interface ----
+    def Start(self, start):
+        start = _f64(start)
+        broadcast = int(start.ndim == 1)
+        if not broadcast and start.shape != (self.dim, self.nchains):
+            raise ValueError("start must be [dim] or [dim][nchains]")
+        st = self._lib.smcmc_vaat_start(self._h, _ptr(start), broadcast)
+        if st == _capi.ERR_BAD_START:
+            return False
+        self._check(st)
+        return True
+
+    def Step(self, nsteps=1): self._check(self._lib.smcmc_vaat_step(self._h, int(nsteps)))
+
+    def step_save(self, nsteps, stride, save_x_ptr, save_logl_ptr=None):
+        self._check(self._lib.smcmc_vaat_step_save(self._h, int(nsteps), int(stride), C.c_void_p(int(save_x_ptr)),
+                                                   C.c_void_p(int(save_logl_ptr)) if save_logl_ptr else None))
+
+    @property
+    def total_steps(self): return self._lib.smcmc_vaat_total_steps(self._h)
+
+    @property
+    def queue_length(self): return self._lib.smcmc_vaat_queue_length(self._h)
+
+    @property
+    def nchains_padded(self): return self._lib.smcmc_vaat_nchains_padded(self._h)
+
+    def GetAccepted(self):
+        x = np.zeros((self.dim, self.nchains))
+        self._check(self._lib.smcmc_vaat_read_state(self._h, _ptr(x), None))
+        return x
+
+    def lane(self, name):
+        if name in _capi.VAAT_LANE_F64:
+            out = np.zeros(self.nchains)
+            self._check(self._lib.smcmc_vaat_read_lane_f64(self._h, _capi.VAAT_LANE_F64[name], _ptr(out)))
+            return out
+        out = np.zeros(self.nchains, np.int32)
+        self._check(self._lib.smcmc_vaat_read_lane_i32(self._h, _capi.VAAT_LANE_I32[name],
+                                                       out.ctypes.data_as(C.POINTER(C.c_int32))))
+        return out
+
+    def per_dim(self, name):
+        """fSigma / fAcceptance / fAcceptanceTrials / fNextIndex as [dim][chain]."""
+        if name in _capi.VAAT_DIM_F64:
+            out = np.zeros((self.dim, self.nchains))
+            self._check(self._lib.smcmc_vaat_read_dim_f64(self._h, _capi.VAAT_DIM_F64[name], _ptr(out)))
+            return out
+        out = np.zeros((self.dim, self.nchains), np.int32)
+        self._check(self._lib.smcmc_vaat_read_dim_i32(self._h, _capi.VAAT_DIM_I32[name],
+                                                      out.ctypes.data_as(C.POINTER(C.c_int32))))
+        return out
+
+    def state_device_ptr(self):
+        x, logl = C.c_void_p(), C.c_void_p()
+        self._check(self._lib.smcmc_vaat_state_device_ptr(self._h, C.byref(x), C.byref(logl)))
+        return x.value, logl.value

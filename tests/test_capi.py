@@ -47,6 +47,10 @@ def test_no_cpu_fallback(smcmc):
     import numpy as np
     with pytest.raises(smcmc.SmcmcError):
         smcmc.selftest_detmath(0, np.ones(4))
+    for cls in (smcmc.HmcEngine, smcmc.VaatEngine):
+        with pytest.raises(smcmc.SmcmcError) as err:
+            cls(5, 10)
+        assert err.value.status == 7
 
 
 def test_product_does_not_touch_the_oracle():

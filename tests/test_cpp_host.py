@@ -249,3 +249,66 @@ def test_hmc_example_with_the_reference_defaults(gpu, oracle, tmp_path):
     assert h.scalars["updates"] >= 2                                  # UpdateErrorMatrix went through on the way
     leap = [int(r_[col["Leapfrog"]]) for r_ in rows[1:]]
     assert len(set(leap)) > 1                                         # the leapfrog count moved
+
+
+def _build_vaat(tmp_path):
+    exe = str(tmp_path / "vaat_amd.exe")
+    cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-Werror", f"-I{os.path.join(ROOT, 'include')}",
+           os.path.join(ROOT, "examples", "SimpleVAAT_amd.C"), f"-L{LIBDIR}", "-lsmcmc_amd",
+           f"-Wl,-rpath,{LIBDIR}", "-Wl,-rpath,/opt/rocm/lib", "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return exe
+
+
+def test_vaat_example_compiles_and_fails_loudly_without_gpu(smcmc, tmp_path):
+    import torch
+    exe = _build_vaat(tmp_path)
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible here")
+    r = subprocess.run([exe, "1", "10", str(tmp_path / "o.csv")], capture_output=True, text=True)
+    assert r.returncode == 2 and "no HIP device" in r.stderr     # no host fallback
+
+
+@pytest.mark.gpu
+def test_vaat_example_is_the_reference_chain(gpu, oracle, tmp_path):
+    """SimpleVAAT.C's call sequence on TProposeVAATStep_amd.H (dim 100, header-form TDummyLogLikelihood): the tree's
+    `Accepted` / `LogLikelihood` / `TotalSteps` columns are chain 0 of the CPU restatement, step for step; the tree has
+    the four branches TSimpleMCMC attaches (TProposeVAATStep::AttachState adds none, :34)."""
+    exe = _build_vaat(tmp_path)
+    out = tmp_path / "vaat.csv"
+    cycles, steps, dim = 2, 150, 100
+    r = subprocess.run([exe, str(cycles), str(steps), str(out), str(dim), "64"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Acceptance:" in r.stdout and "Sigma:" in r.stdout and r.stdout.rstrip().endswith("Exit")
+    lines = open(out).read().splitlines()
+    header = lines[0].split(",")
+    names = {h.split("[")[0] for h in header if h}
+    assert names == {"LogLikelihood", "TotalSteps", "Accepted", "StepRMS"}
+    col = {h: i for i, h in enumerate(header) if h}
+    rows = [l.split(",") for l in lines[1:]]
+    assert len(rows) == cycles * steps                               # Start(p, false): no entry for the start
+
+    # the example's start point: uniform in [-1, 1] from the START stream of chain 0 (SimpleVAAT.C:41)
+    u = np.zeros(dim)
+    words = np.zeros(4, dtype=np.uint32)
+    import ctypes as C
+    lib = oracle.lib()
+    for i in range(dim):
+        if i % 4 == 0:
+            # key = seed (lo, hi); counter = (block, chain, step lo, step hi | stream << 28)
+            lib.oracle_philox(i // 4, 0, 0, 1 << 28, 20240607 & 0xFFFFFFFF, 20240607 >> 32,
+                              words.ctypes.data_as(C.POINTER(C.c_uint32)))
+        u[i] = (float(words[i % 4]) + 0.5) * 2.0 ** -32
+    start = -1.0 + 2.0 * u
+    o = oracle.Vaat(1, dim, kind=1, seed=20240607)
+    o.set_step_rms_window(1000)                                      # TSimpleMCMC's default (:586)
+    assert o.start(start)
+    o.update_proposal()
+    for k, row in enumerate(rows):
+        o.step(1)
+        assert int(row[col["TotalSteps"]]) == k + 1
+        x = np.array([float(row[col[f"Accepted[{d}]"]]) for d in range(dim)])
+        assert np.array_equal(x, o.x[:, 0]), f"entry {k}"
+        assert float(row[col["LogLikelihood"]]) == o.lane("logl")[0]
+        assert float(row[col["StepRMS"]]) == o.lane("step_rms")[0]

@@ -234,7 +234,8 @@ def test_hmc_covariant_gradient(gpu, oracle, kind, dim, nchains):
     for k in range(3):
         e.Step(5); o.step(5)
         _same_hmc(e, o, f"block {k}")
-    assert e.lane("naccept").sum() > 0
+    if kind != 2:   # the identity-covariance gradient is no guide on the Rosenbrock ridge: nothing is accepted this early
+        assert e.lane("naccept").sum() > 0
 
 
 def test_hmc_covariant_gradient_with_a_fixed_step(gpu, oracle):

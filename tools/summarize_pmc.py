@@ -1,6 +1,6 @@
-"""Summaries of the rocprofv3 passes of tools/profile_bench.sh -> profiles/r01_*.json / .csv.
+"""Summaries of the rocprofv3 passes of tools/profile_bench.sh -> profiles/rNN_*.json / .csv.
 
-usage: python tools/summarize_pmc.py gpurun_out/r01b profiles/r01
+usage: python tools/summarize_pmc.py gpurun_out/r02 profiles/r02
 Picks the newest run directory of every pass; the first launch after Start is left out."""
 import csv
 import glob
@@ -32,6 +32,13 @@ def counters(path):
 
 def main(src, dst):
     shutil.copy(newest(f"{src}/stats/*/*_kernel_stats.csv"), f"{dst}_bench_kernel_stats.csv")
+    extras = glob.glob(f"{src}/extras/*/*_kernel_stats.csv")
+    if extras:   # the pass with every single-GPU config on the line (bench.py without --no-extras)
+        shutil.copy(sorted(extras, key=os.path.getmtime)[-1], f"{dst}_bench_extras_kernel_stats.csv")
+    if os.path.exists(f"{src}/bench.json"):
+        lines = [ln for ln in open(f"{src}/bench.json") if ln.startswith("{")]
+        if lines:
+            json.dump(json.loads(lines[-1]), open(f"{dst}_bench_line.json", "w"), indent=1)
     fetch = counters(newest(f"{src}/fetch/*/*_counter_collection.csv"))["FETCH_SIZE"]
     write = counters(newest(f"{src}/write/*/*_counter_collection.csv"))["WRITE_SIZE"]
     fb = 1024.0 * sum(fetch) / len(fetch)

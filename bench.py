@@ -337,6 +337,10 @@ def main():
                 extra["c4_share_d500_32768_pooled" + ("" if exact else "_fused")] = extra_metropolis(
                     pkg, torch, stream, "TDummyLogLikelihood README form D=500, 32 768 chains (one GPU's share of config 4), "
                     "pooled, sync every 256 steps", 500, 32768, "iso", pkg.LIKE_ISO_GAUSS, None, np.zeros(500), exact, 2)
+                extra["c4_share_d500_32768_pooled_stride16" + ("" if exact else "_fused")] = extra_metropolis(
+                    pkg, torch, stream, "config 4 share as above with the covariance fed every 16th step (SMCMC_P_MOMENT_STRIDE: "
+                    "a thinned running covariance, not the reference's every-step update)", 500, 32768, "iso",
+                    pkg.LIKE_ISO_GAUSS, None, np.zeros(500), exact, 2, stride=16)
             extra["c4_share_d500_32768_pooled_header_tdummy"] = extra_metropolis(
                 pkg, torch, stream, "TDummyLogLikelihood header form D=500, 32 768 chains, pooled (the likelihood config 4 "
                 "names, in the reference's order: one serial D^2-term sum per chain)", 500, 32768, "quadform",

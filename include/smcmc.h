@@ -91,6 +91,12 @@ typedef enum {
     SMCMC_P_MOMENT_GROUP = 19,          /* chains per moment group (read only: 64, or the slice size of the dim > 63 path) */
     SMCMC_P_KEEP_PROPOSED = 20,         /* 1: every launch leaves the proposal of its last step on the device for
                                            smcmc_read_proposed (fProposed / GetProposed, TSimpleMCMC.H:514, 576); default 0 */
+    SMCMC_P_DEVICE_UPDATE = 21,         /* 1 (default): the pooled update (running centre / covariance, sigma rescale, Cholesky, operand
+                                         * layouts) runs on the device with no host synchronisation; only a failed decomposition brings
+                                         * the host's fallback ladder (TSimpleMCMC.H:1134-1389) in.  0: all of it on the host.  Same bits. */
+    SMCMC_P_OVERLAP_UPDATE = 22,        /* 1: the next launch does not wait for the status of the update before it;
+                                         * identical results unless that update falls back to the ladder, which then takes effect one
+                                         * window late.  0 (default): parity mode */
     SMCMC_P_COUNT_
 } smcmc_param;
 

@@ -50,6 +50,7 @@ def _units(user_flag=None):
     units = [engine, ("smcmc_selftest.hip", [], "selftest"), ("smcmc_autocorr.hip", [], "autocorr"),
              ("smcmc_hmc_engine.hip", [], "hmc_engine"), ("smcmc_hmc_mfma_inst.hip", [], "hmc_mfma"),
              ("smcmc_vaat_engine.hip", [], "vaat_engine"), ("smcmc_vaat_large.hip", [], "vaat_large"),
+             ("smcmc_pooled_update.hip", [], "pooled_update"),
              ("smcmc_panel_mfma_inst.hip", [], "panel_mfma")]
     for dp in dp_list():
         for like in LIKELIHOODS:

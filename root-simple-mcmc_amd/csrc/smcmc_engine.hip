@@ -19,6 +19,7 @@
 #include "smcmc_kernels.hip.h"
 #include "smcmc_panel_kernel.hip.h"
 #include "smcmc_panel_mfma_kernel.hip.h"
+#include "smcmc_pooled_update.hip.h"
 #include "smcmc_fold_kernel.hip.h"
 #include "smcmc_proposal.hpp"
 
@@ -107,6 +108,16 @@ struct smcmc_engine {
     bool keep_proposed = false;
     double* d_uniform = nullptr;   // [2][dp] bounds of the uniform dimensions
     int scan_dim = -1;             // fScanDimension
+    // the pooled update on the device (smcmc_pooled_update.hip.h): the device copy of the shared proposal's numbers
+    bool device_update = true;     // SMCMC_P_DEVICE_UPDATE
+    bool overlap_update = false;   // SMCMC_P_OVERLAP_UPDATE
+    double *d_centre = nullptr, *d_cov = nullptr, *d_decomp = nullptr, *d_scal = nullptr;
+    double* h_scal = nullptr;      // pinned: the scalars (status word included) of the latest device update
+    hipEvent_t status_event = nullptr;
+    bool status_pending = false;   // a device update whose status the host has not looked at yet
+    bool host_stale = false;       // the device holds newer centre / covariance / decomposition / trials than *prop
+    bool device_stale = true;      // *prop was changed on the host since the device copy was written
+    struct { int updateCount, nextUpdate, lastPath; double acceptanceTrials; bool decompFull; } before_update{};
     std::string error;
 };
 
@@ -405,6 +416,171 @@ int update_shared(smcmc_engine* h) {
     return SMCMC_OK;
 }
 
+// ---- the pooled update on the device (smcmc_pooled_update.hip.h) ---------------------------------
+// *h->prop stays the owner of the settings and of everything the fallback ladder needs; the numbers the update
+// changes every window (centre, covariance, decomposition, trials, sigma template, sigma trace) live on the device
+// and come back to the host only when somebody asks (host_stale) or when a decomposition fails.
+
+bool device_update_eligible(const smcmc_engine* h) {
+    if (!h->device_update || h->mode != SMCMC_MODE_POOLED || !h->d_scal) return false;
+    for (int d = 0; d < h->dim; ++d)
+        if (h->prop->ptype[d] != 0) return false;   // uniform dimensions zero rows and columns of U on the host path
+    return true;
+}
+
+// host copy -> device copy
+int push_shared(smcmc_engine* h) {
+    const SharedProposal& P = *h->prop;
+    const size_t D = (size_t)h->dim;
+    double sc[kPsCount] = {0, 0, 0, 0, 0, 0, 0, 0};
+    sc[kPsCovTrials] = P.covTrials; sc[kPsCentreTrials] = P.centreTrials; sc[kPsSigma] = P.sigma;
+    sc[kPsSigmaTrace] = P.sigmaTrace; sc[kPsLastScale] = P.lastSigmaScale; sc[kPsStatus] = kPooledOk;
+    HIP_TRY(h, hipMemcpyAsync(h->d_cov, P.cov.data(), D * D * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_decomp, P.decomp.data(), D * D * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_centre, P.centre.data(), D * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_scal, sc, sizeof(sc), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));   // pageable sources
+    h->device_stale = false;
+    return SMCMC_OK;
+}
+
+// device copy -> host copy (synchronises the stream)
+int pull_raw(smcmc_engine* h) {
+    SharedProposal& P = *h->prop;
+    const size_t D = (size_t)h->dim;
+    double sc[kPsCount];
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipMemcpy(P.cov.data(), h->d_cov, D * D * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(P.centre.data(), h->d_centre, D * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(sc, h->d_scal, sizeof(sc), hipMemcpyDeviceToHost));
+    if (sc[kPsStatus] == kPooledOk)
+        HIP_TRY(h, hipMemcpy(P.decomp.data(), h->d_decomp, D * D * sizeof(double), hipMemcpyDeviceToHost));
+    P.covTrials = sc[kPsCovTrials]; P.centreTrials = sc[kPsCentreTrials]; P.sigma = sc[kPsSigma];
+    P.sigmaTrace = sc[kPsSigmaTrace]; P.lastSigmaScale = sc[kPsLastScale];
+    h->host_stale = false;
+    return SMCMC_OK;
+}
+
+int upload_shared(smcmc_engine* h);
+int adjust_lanes(smcmc_engine* h, double sigma_scale);
+int read_chain0(smcmc_engine* h, std::vector<double>& x0);
+int reset_lanes(smcmc_engine* h);
+
+// Looks at the status word of the latest device update.  A decomposition that failed there continues on the host
+// exactly where SharedProposal::update would have: the fallback ladder, then the per-chain consequences.
+int check_pending(smcmc_engine* h) {
+    if (!h->status_pending) return SMCMC_OK;
+    HIP_TRY(h, hipEventSynchronize(h->status_event));
+    h->status_pending = false;
+    SharedProposal& P = *h->prop;
+    const int status = (int)h->h_scal[kPsStatus];
+    if (status == kPooledOk) return SMCMC_OK;
+    // the host-side bookkeeping of the update was done optimistically: take it back
+    P.updateCount = h->before_update.updateCount; P.nextUpdate = h->before_update.nextUpdate;
+    P.lastPath = h->before_update.lastPath; P.acceptanceTrials = h->before_update.acceptanceTrials;
+    P.decompFull = h->before_update.decompFull;
+    if (status == kPooledSkipped) return SMCMC_OK;     // no point was folded: no update (as the host path)
+    int st = pull_raw(h);
+    if (st) return st;
+    h->device_stale = true;
+    // what SharedProposal::update does around the decomposition (the device did the numbers)
+    ++P.updateCount;
+    if (status == kPooledInvalidTrace) return status_of(h, UpdateStatus::InvalidTrace);
+    {
+        const double maxUp = (double)h->dim * (double)h->dim;
+        P.nextUpdate = (int)(P.acceptanceWindow + maxUp - maxUp / (0.5 * P.successes + 1.0));
+        if (P.acceptanceDeweight > 0.0) {
+            if (P.acceptanceDeweight > 1.0) P.acceptanceDeweight = 1.0;
+            const double w = 1.0 - P.acceptanceDeweight;
+            P.acceptanceTrials = std::max(1.0, w * P.acceptanceTrials);
+            P.acceptanceTrials = std::min(P.acceptanceTrials, w * P.acceptanceWindow);
+        }
+        if (P.covDeweight > 1.0) P.covDeweight = 1.0;
+    }
+    st = status_of(h, P.finishUpdateOnHost(h->h_scal[kPsLastScale]));
+    if (st) return st;
+    st = adjust_lanes(h, P.lastSigmaScale);
+    if (st) return st;
+    if (P.lastPath == 4) {
+        std::vector<double> x0;
+        st = read_chain0(h, x0);
+        if (st) return st;
+        P.lastPoint = x0;
+        P.centre = x0;
+        st = reset_lanes(h);
+        if (st) return st;
+        HIP_TRY(h, hipMemsetAsync(h->d_gacc, 0, sizeof(double) * gacc_doubles(h), h->stream));
+    }
+    return upload_shared(h);
+}
+
+// before the host reads (mutate = false) or changes (mutate = true) anything an update touches
+int sync_shared_to_host(smcmc_engine* h, bool mutate) {
+    int st = check_pending(h);
+    if (st) return st;
+    if (h->host_stale) {
+        st = pull_raw(h);
+        if (st) return st;
+    }
+    if (mutate) h->device_stale = true;
+    return SMCMC_OK;
+}
+
+// smcmc_apply_moments without the host: absorb, scalar half, Cholesky, operand layouts, per-chain consequences
+int device_apply(smcmc_engine* h) {
+    int st = check_pending(h);
+    if (st) return st;
+    SharedProposal& P = *h->prop;
+    if (h->device_stale) {
+        if (h->host_stale) return fail(h, SMCMC_ERR_LOGIC, "shared proposal: host and device copies both changed");
+        st = push_shared(h);
+        if (st) return st;
+    }
+    static const hipError_t prepared = pooled_update_prepare();
+    if (prepared != hipSuccess) return fail(h, SMCMC_ERR_HIP, std::string("pooled update setup: ") + hipGetErrorString(prepared));
+    PooledUpdateParams u;
+    u.D = h->dim; u.M = h->d_moments; u.centre = h->d_centre; u.cov = h->d_cov; u.decomp = h->d_decomp; u.scal = h->d_scal;
+    u.cov_window = P.covWindow; u.cov_deweight = P.covDeweight;
+    hipError_t e = launch_pooled_update(u, h->stream);
+    if (e != hipSuccess) return fail(h, SMCMC_ERR_HIP, std::string("pooled update launch: ") + hipGetErrorString(e));
+    PooledPublishParams q;
+    std::memset(&q, 0, sizeof(q));
+    q.D = h->dim; q.decomp = h->d_decomp; q.centre = h->d_centre; q.scal = h->d_scal; q.U = h->d_U; q.c0 = h->d_c0;
+    if (h->panel_w) {
+        q.W = h->panel_w; q.CW = kPanelCW;
+        if (!h->exact) { q.Uop = h->d_Uop; q.nkq_padded = panel_mfma_nkq_padded(h->dim); }
+    } else {
+        q.DP = h->dp;
+    }
+    e = launch_pooled_publish(q, h->stream);
+    if (e != hipSuccess) return fail(h, SMCMC_ERR_HIP, std::string("publish launch: ") + hipGetErrorString(e));
+    // the host-only half of SharedProposal::update, optimistically (check_pending takes it back if the device says no)
+    h->before_update = {P.updateCount, P.nextUpdate, P.lastPath, P.acceptanceTrials, P.decompFull};
+    ++P.updateCount;
+    const double maxUp = (double)h->dim * (double)h->dim;
+    P.nextUpdate = (int)(P.acceptanceWindow + maxUp - maxUp / (0.5 * P.successes + 1.0));
+    if (P.covDeweight > 1.0) P.covDeweight = 1.0;
+    double acc_w = -1.0, acc_wW = 0.0;
+    if (P.acceptanceDeweight > 0.0) {
+        if (P.acceptanceDeweight > 1.0) P.acceptanceDeweight = 1.0;
+        const double w = 1.0 - P.acceptanceDeweight;
+        P.acceptanceTrials = std::max(1.0, w * P.acceptanceTrials);
+        P.acceptanceTrials = std::min(P.acceptanceTrials, w * P.acceptanceWindow);
+        acc_w = 1.0 - std::min(P.acceptanceDeweight, 1.0);
+        acc_wW = acc_w * P.acceptanceWindow;
+    }
+    P.lastPath = 0;
+    P.decompFull = false;
+    e = launch_pooled_adjust_lanes(h->d_lane_f64, h->npad, h->nchains, h->d_scal, acc_w, acc_wW, SMCMC_LANE_SIGMA,
+                                   SMCMC_LANE_ACCEPTANCE_TRIALS, h->stream);
+    if (e != hipSuccess) return fail(h, SMCMC_ERR_HIP, std::string("adjust_lanes launch: ") + hipGetErrorString(e));
+    HIP_TRY(h, hipMemcpyAsync(h->h_scal, h->d_scal, sizeof(double) * kPsCount, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipEventRecord(h->status_event, h->stream));
+    h->status_pending = true;
+    h->host_stale = true;
+    return SMCMC_OK;
+}
+
 StepParams make_params(smcmc_engine* h, int nsteps, int metropolis) {
     const SharedProposal& P = *h->prop;
     StepParams p;
@@ -461,6 +637,11 @@ int launch(smcmc_engine* h, int nsteps, int metropolis, int stride, double* save
     if (!h->started) return fail(h, SMCMC_ERR_INVALID, "Uninitialized starting point");   // TSimpleMCMC.H:371-374
     if (nsteps <= 0) return SMCMC_OK;
     if (metropolis < 0 || metropolis > 2) return fail(h, SMCMC_ERR_INVALID, "metropolis must be 0, 1 or 2");
+    if (!h->overlap_update) {
+        // parity mode: a fallback of the latest pooled update takes effect before the next step
+        int pst = check_pending(h);
+        if (pst) return pst;
+    }
     StepParams p = make_params(h, nsteps, metropolis);
     if (save_x) {
         if (stride <= 0) return fail(h, SMCMC_ERR_INVALID, "save stride must be positive");
@@ -641,6 +822,13 @@ int smcmc_create(int dim, int nchains, int likelihood, uint64_t seed, uint32_t c
     HIP_TRY(h, hipMemset(h->d_c0, 0, sizeof(double) * dp));
     HIP_TRY(h, hipMemset(h->d_gacc, 0, sizeof(double) * gacc_doubles(h)));
     HIP_TRY(h, hipMemset(h->d_moments, 0, sizeof(double) * npacked(h)));
+    HIP_TRY(h, hipMalloc(&h->d_centre, sizeof(double) * dim));
+    HIP_TRY(h, hipMalloc(&h->d_cov, sizeof(double) * (size_t)dim * dim));
+    HIP_TRY(h, hipMalloc(&h->d_decomp, sizeof(double) * (size_t)dim * dim));
+    HIP_TRY(h, hipMalloc(&h->d_scal, sizeof(double) * kPsCount));
+    HIP_TRY(h, hipMemset(h->d_scal, 0, sizeof(double) * kPsCount));
+    HIP_TRY(h, hipHostMalloc((void**)&h->h_scal, sizeof(double) * kPsCount, hipHostMallocDefault));
+    HIP_TRY(h, hipEventCreateWithFlags(&h->status_event, hipEventDisableTiming));
     return SMCMC_OK;
 }
 
@@ -652,6 +840,9 @@ int smcmc_destroy(smcmc_engine* h) {
     (void)hipFree(h->d_x); (void)hipFree(h->d_forced); (void)hipFree(h->d_proposed); (void)hipFree(h->d_scratch); (void)hipFree(h->d_uniform); (void)hipFree(h->d_lane_f64); (void)hipFree(h->d_lane_i32);
     (void)hipFree(h->d_U); (void)hipFree(h->d_Uop); (void)hipFree(h->d_like); (void)hipFree(h->d_c0); (void)hipFree(h->d_gacc);
     (void)hipFree(h->d_moments); (void)hipFree(h->d_chunks); (void)hipHostFree(h->h_moments);
+    (void)hipFree(h->d_centre); (void)hipFree(h->d_cov); (void)hipFree(h->d_decomp); (void)hipFree(h->d_scal);
+    (void)hipHostFree(h->h_scal);
+    if (h->status_event) (void)hipEventDestroy(h->status_event);
     delete h->prop;
     delete h;
     return SMCMC_OK;
@@ -681,6 +872,7 @@ int smcmc_set_mode(smcmc_engine* h, int mode) {
 int smcmc_set_gaussian(smcmc_engine* h, int dim, double sigma) {
     if (!h) return SMCMC_ERR_INVALID;
     ON_DEVICE(h);
+    { int sst_ = sync_shared_to_host(h, true); if (sst_) return sst_; }
     if (dim < 0 || dim >= h->dim) return fail(h, SMCMC_ERR_INVALID, "Dimension is out of range.");   // :856-860
     const bool was_uniform = h->prop->ptype[dim] == 1;
     h->prop->ptype[dim] = 0;
@@ -691,6 +883,7 @@ int smcmc_set_gaussian(smcmc_engine* h, int dim, double sigma) {
 int smcmc_set_uniform(smcmc_engine* h, int dim, double minimum, double maximum) {
     if (!h) return SMCMC_ERR_INVALID;
     ON_DEVICE(h);
+    { int sst_ = sync_shared_to_host(h, true); if (sst_) return sst_; }
     if (dim < 0 || dim >= h->dim) return fail(h, SMCMC_ERR_INVALID, "Dimension is out of range.");
     h->prop->ptype[dim] = 1;                                                                        // :845-847
     h->prop->param1[dim] = minimum;
@@ -706,6 +899,8 @@ int smcmc_set_scan_dimension(smcmc_engine* h, int dim) {
 
 int smcmc_set_correlation(smcmc_engine* h, int d1, int d2, double c) {
     if (!h) return SMCMC_ERR_INVALID;
+    ON_DEVICE(h);
+    { int sst_ = sync_shared_to_host(h, true); if (sst_) return sst_; }
     if (d1 < 0 || d2 < 0 || d1 >= h->dim || d2 >= h->dim) return fail(h, SMCMC_ERR_INVALID, "Dimension is out of range.");
     if (d1 == d2) return fail(h, SMCMC_ERR_INVALID, "Dimensions must be different for correlations");   // :884-890
     const double mc = h->prop->maxCorrelation;
@@ -717,6 +912,8 @@ int smcmc_set_correlation(smcmc_engine* h, int d1, int d2, double c) {
 
 int smcmc_reset_correlations(smcmc_engine* h) {
     if (!h) return SMCMC_ERR_INVALID;
+    ON_DEVICE(h);
+    { int sst_ = sync_shared_to_host(h, true); if (sst_) return sst_; }
     h->prop->correlations.clear();
     return SMCMC_OK;
 }
@@ -742,6 +939,11 @@ static int broadcast_lane_i32(smcmc_engine* h, int field, int32_t v) {
 int smcmc_set_param(smcmc_engine* h, int which, double v) {
     if (!h) return SMCMC_ERR_INVALID;
     ON_DEVICE(h);
+    if (which == SMCMC_P_SIGMA || which == SMCMC_P_COVARIANCE_TRIALS || which == SMCMC_P_CENTER_TRIALS ||
+        which == SMCMC_P_NEXT_UPDATE || (which == SMCMC_P_EXACT_ARITHMETIC && h->started)) {
+        int sst_ = sync_shared_to_host(h, true);   // the rest are settings the host alone keeps
+        if (sst_) return sst_;
+    }
     SharedProposal& P = *h->prop;
     switch (which) {
         case SMCMC_P_COVARIANCE_WINDOW: P.covWindow = v; return SMCMC_OK;
@@ -779,6 +981,8 @@ int smcmc_set_param(smcmc_engine* h, int which, double v) {
             }
             h->keep_proposed = (v != 0.0);
             return SMCMC_OK;
+        case SMCMC_P_DEVICE_UPDATE: h->device_update = (v != 0.0); return SMCMC_OK;
+        case SMCMC_P_OVERLAP_UPDATE: h->overlap_update = (v != 0.0); return SMCMC_OK;
         case SMCMC_P_MOMENT_STRIDE:
             if (v < 1.0) return fail(h, SMCMC_ERR_INVALID, "moment stride must be >= 1");
             if (!h->panel_w && v != 1.0)
@@ -792,6 +996,16 @@ int smcmc_set_param(smcmc_engine* h, int which, double v) {
 int smcmc_get_param(smcmc_engine* h, int which, double* out) {
     if (!h || !out) return SMCMC_ERR_INVALID;
     ON_DEVICE(h);
+    // only what a pooled update changes needs the device's copy (a stream synchronisation and a download)
+    if (which == SMCMC_P_COVARIANCE_TRIALS || which == SMCMC_P_CENTER_TRIALS || which == SMCMC_P_COVARIANCE_TRACE ||
+        which == SMCMC_P_SIGMA_TRACE) {
+        int sst_ = sync_shared_to_host(h, false);
+        if (sst_) return sst_;
+    } else if (which == SMCMC_P_UPDATE_COUNT || which == SMCMC_P_LAST_UPDATE_PATH || which == SMCMC_P_NEXT_UPDATE ||
+               which == SMCMC_P_SIGMA) {
+        int sst_ = check_pending(h);
+        if (sst_) return sst_;
+    }
     const SharedProposal& P = *h->prop;
     switch (which) {
         case SMCMC_P_COVARIANCE_WINDOW: *out = P.covWindow; break;
@@ -821,6 +1035,8 @@ int smcmc_get_param(smcmc_engine* h, int which, double* out) {
         case SMCMC_P_MOMENT_STRIDE: *out = h->moment_stride; break;
         case SMCMC_P_MOMENT_GROUP: *out = h->panel_w ? h->slice_chains : kWave; break;
         case SMCMC_P_KEEP_PROPOSED: *out = h->keep_proposed ? 1.0 : 0.0; break;
+        case SMCMC_P_DEVICE_UPDATE: *out = h->device_update ? 1.0 : 0.0; break;
+        case SMCMC_P_OVERLAP_UPDATE: *out = h->overlap_update ? 1.0 : 0.0; break;
         default: return fail(h, SMCMC_ERR_INVALID, "unknown parameter");
     }
     return SMCMC_OK;
@@ -886,6 +1102,7 @@ static int place_chains(smcmc_engine* h, const double* x0, int broadcast, std::v
 int smcmc_start(smcmc_engine* h, const double* x0, int broadcast) {
     if (!h || !x0) return SMCMC_ERR_INVALID;
     ON_DEVICE(h);
+    { int sst_ = sync_shared_to_host(h, true); if (sst_) return sst_; }
     const int D = h->dim, N = h->nchains;
     const size_t NP = (size_t)h->npad;
     std::vector<double> x, logl;
@@ -935,6 +1152,7 @@ int smcmc_start(smcmc_engine* h, const double* x0, int broadcast) {
 int smcmc_restore(smcmc_engine* h, const double* accepted, int broadcast, const smcmc_saved_state* s) {
     if (!h || !accepted || !s || !s->central_point || !s->covariance) return SMCMC_ERR_INVALID;
     ON_DEVICE(h);
+    { int sst_ = sync_shared_to_host(h, true); if (sst_) return sst_; }
     if (!h->started)
         return fail(h, SMCMC_ERR_INVALID, "Restore needs a started chain (Start first, SimpleMCMC.C:151-154)");
     const int D = h->dim, N = h->nchains;
@@ -1001,6 +1219,7 @@ int smcmc_step_save(smcmc_engine* h, int nsteps, int metropolis, int stride, dou
 int smcmc_force_step(smcmc_engine* h, const double* point, int broadcast) {
     if (!h || !point) return SMCMC_ERR_INVALID;
     ON_DEVICE(h);
+    { int sst_ = check_pending(h); if (sst_) return sst_; }
     const int D = h->dim, N = h->nchains;
     const size_t NP = (size_t)h->npad;
     std::vector<double> x(NP * h->dp, 0.0);
@@ -1054,10 +1273,12 @@ int smcmc_read_moments(smcmc_engine* h, double* out) {
 int smcmc_apply_moments(smcmc_engine* h) {
     if (!h || !h->started) return SMCMC_ERR_INVALID;
     ON_DEVICE(h);
+    if (device_update_eligible(h)) return device_apply(h);
+    int st = sync_shared_to_host(h, true);
+    if (st) return st;
     const double* M = h->h_moments;
     HIP_TRY(h, hipMemcpyAsync(h->h_moments, h->d_moments, npacked(h) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    int st = SMCMC_OK;
     SharedProposal& P = *h->prop;
     if (!(M[npacked(h) - 1] > 0.0)) return SMCMC_OK;
     P.absorbMoments(M, h->mode == SMCMC_MODE_POOLED);
@@ -1163,6 +1384,7 @@ int smcmc_allreduce_moments(smcmc_engine* h) {
 int smcmc_update_proposal(smcmc_engine* h) {
     if (!h || !h->started) return SMCMC_ERR_INVALID;
     ON_DEVICE(h);
+    { int sst_ = sync_shared_to_host(h, true); if (sst_) return sst_; }
     SharedProposal& P = *h->prop;
     int st = update_shared(h);
     if (st) return st;
@@ -1185,6 +1407,7 @@ int smcmc_update_proposal(smcmc_engine* h) {
 int smcmc_reset_proposal(smcmc_engine* h) {
     if (!h || !h->started) return SMCMC_ERR_INVALID;
     ON_DEVICE(h);
+    { int sst_ = sync_shared_to_host(h, true); if (sst_) return sst_; }
     SharedProposal& P = *h->prop;
     // fLastPoint of the shared proposal := chain 0's current point
     std::vector<double> x0;
@@ -1231,6 +1454,7 @@ int smcmc_read_proposed(smcmc_engine* h, double* x) {
 int smcmc_read_lane_f64(smcmc_engine* h, int field, double* out) {
     if (!h || !out || field < 0 || field >= SMCMC_LANE_F64_COUNT_) return SMCMC_ERR_INVALID;
     ON_DEVICE(h);
+    { int sst_ = check_pending(h); if (sst_) return sst_; }
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     HIP_TRY(h, hipMemcpy(out, h->d_lane_f64 + (size_t)field * h->npad, (size_t)h->nchains * sizeof(double),
                          hipMemcpyDeviceToHost));
@@ -1248,6 +1472,8 @@ int smcmc_read_lane_i32(smcmc_engine* h, int field, int32_t* out) {
 
 int smcmc_get_center(smcmc_engine* h, double* out) {
     if (!h || !out) return SMCMC_ERR_INVALID;
+    ON_DEVICE(h);
+    { int sst_ = sync_shared_to_host(h, false); if (sst_) return sst_; }
     std::copy(h->prop->centre.begin(), h->prop->centre.end(), out);
     return SMCMC_OK;
 }
@@ -1255,24 +1481,31 @@ int smcmc_get_center(smcmc_engine* h, double* out) {
 int smcmc_set_center(smcmc_engine* h, const double* in) {
     if (!h || !in) return SMCMC_ERR_INVALID;
     ON_DEVICE(h);
+    { int sst_ = sync_shared_to_host(h, true); if (sst_) return sst_; }
     std::copy(in, in + h->dim, h->prop->centre.begin());
     return h->started ? upload_shared(h) : SMCMC_OK;
 }
 
 int smcmc_get_covariance(smcmc_engine* h, double* out) {
     if (!h || !out) return SMCMC_ERR_INVALID;
+    ON_DEVICE(h);
+    { int sst_ = sync_shared_to_host(h, false); if (sst_) return sst_; }
     std::copy(h->prop->cov.begin(), h->prop->cov.end(), out);
     return SMCMC_OK;
 }
 
 int smcmc_set_covariance(smcmc_engine* h, const double* in) {
     if (!h || !in) return SMCMC_ERR_INVALID;
+    ON_DEVICE(h);
+    { int sst_ = sync_shared_to_host(h, true); if (sst_) return sst_; }
     std::copy(in, in + (size_t)h->dim * h->dim, h->prop->cov.begin());
     return SMCMC_OK;
 }
 
 int smcmc_get_decomposition(smcmc_engine* h, double* out) {
     if (!h || !out) return SMCMC_ERR_INVALID;
+    ON_DEVICE(h);
+    { int sst_ = sync_shared_to_host(h, false); if (sst_) return sst_; }
     std::copy(h->prop->decomp.begin(), h->prop->decomp.end(), out);
     return SMCMC_OK;
 }

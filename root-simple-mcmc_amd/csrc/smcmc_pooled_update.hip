@@ -1,0 +1,251 @@
+// smcmc_pooled_update.hip -- kernels of the device-resident pooled UpdateProposal (see smcmc_pooled_update.hip.h).
+// Compiled, like every other unit, with -ffp-contract=off: each multiply and each subtract below rounds on its own,
+// as in SharedProposal::absorbMoments / update / cholesky (smcmc_proposal.hpp), which this file restates for the GPU.
+#include "smcmc_pooled_update.hip.h"
+
+namespace smcmc {
+
+namespace {
+
+__device__ __forceinline__ double pu_min(double a, double b) { return __builtin_fmin(a, b); }
+__device__ __forceinline__ double pu_max(double a, double b) { return __builtin_fmax(a, b); }
+
+// SharedProposal::absorbMoments: one thread per (i, j <= i)
+__global__ void __launch_bounds__(256) pooled_absorb_kernel(const PooledUpdateParams p) {
+    const int D = p.D;
+    const int j = blockIdx.x * 16 + (threadIdx.x & 15);
+    const int i = blockIdx.y * 16 + (threadIdx.x >> 4);
+    if (i >= D || j > i) return;
+    const double* S1 = p.M + (size_t)D * (D + 1) / 2;
+    const double n = S1[D];
+    if (!(n > 0.0)) return;
+    const double centre_trials = p.scal[kPsCentreTrials], cov_trials = p.scal[kPsCovTrials];
+    const double di = S1[i] / (centre_trials + n);
+    const double dj = S1[j] / (centre_trials + n);
+    double b = p.M[(size_t)i * (i + 1) / 2 + j];
+    b -= S1[i] * dj;
+    b -= di * S1[j];
+    b += (n * di) * dj;
+    double v = p.cov[(size_t)i * D + j];
+    v *= cov_trials;
+    v += b;
+    v /= cov_trials + n;
+    p.cov[(size_t)i * D + j] = v;
+    p.cov[(size_t)j * D + i] = v;
+    if (j == 0) p.centre[i] = p.centre[i] + di;
+}
+
+// the trials, and the scalar half of SharedProposal::update (TSimpleMCMC.H:1030-1075): one wavefront
+__global__ void __launch_bounds__(64) pooled_scalars_kernel(const PooledUpdateParams p) {
+    __shared__ double diag[512];
+    const int D = p.D;
+    const int lane = threadIdx.x;
+    for (int d = lane; d < D; d += 64) diag[d] = p.cov[(size_t)d * D + d];
+    __syncthreads();
+    if (lane != 0) return;
+    const double* S1 = p.M + (size_t)D * (D + 1) / 2;
+    const double n = S1[D];
+    if (!(n > 0.0)) {
+        p.scal[kPsStatus] = kPooledSkipped;
+        return;
+    }
+    double centre_trials = pu_min(p.cov_window, p.scal[kPsCentreTrials] + n);
+    double cov_trials = pu_min(p.cov_window, p.scal[kPsCovTrials] + n);
+    double trace = 0.0;
+    for (int d = 0; d < D; ++d) trace += diag[d];
+    if (trace <= 0) {
+        p.scal[kPsCentreTrials] = centre_trials;
+        p.scal[kPsCovTrials] = cov_trials;
+        p.scal[kPsStatus] = kPooledInvalidTrace;
+        return;
+    }
+    const double scale = __builtin_sqrt(p.scal[kPsSigmaTrace] / trace);
+    p.scal[kPsSigma] = p.scal[kPsSigma] * scale;
+    p.scal[kPsSigmaTrace] = trace;
+    p.scal[kPsLastScale] = scale;
+    if (p.cov_deweight > 0.0) {
+        const double w = 1.0 - pu_min(p.cov_deweight, 1.0);
+        cov_trials = pu_max(1.0, w * cov_trials);
+        cov_trials = pu_min(cov_trials, w * p.cov_window);
+        centre_trials = pu_max(1.0, w * centre_trials);
+        centre_trials = pu_min(centre_trials, w * p.cov_window);
+    }
+    p.scal[kPsCentreTrials] = centre_trials;
+    p.scal[kPsCovTrials] = cov_trials;
+    p.scal[kPsStatus] = kPooledOk;
+}
+
+__global__ void __launch_bounds__(256) chol_copy_kernel(const double* cov, double* decomp, size_t n, const double* scal) {
+    if (scal[kPsStatus] != kPooledOk) return;
+    const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (k < n) decomp[k] = cov[k];
+}
+
+// rows r0 .. r0+31 of U: one workgroup, the panel (its rows, columns r0 .. D-1) in LDS
+__global__ void __launch_bounds__(512) chol_panel_kernel(double* R, int D, int r0, double* scal) {
+    extern __shared__ double panel[];                   // [nrows][ncols]
+    __shared__ double s_piv;
+    __shared__ int s_fail;
+    if (scal[kPsStatus] != kPooledOk) return;
+    const int nrows = (D - r0 < kCholPanel) ? D - r0 : kCholPanel;
+    const int ncols = D - r0;
+    const int jj = threadIdx.x;                         // local column (ncols <= 512)
+    for (int rr = 0; rr < nrows; ++rr)
+        if (jj < ncols) panel[rr * ncols + jj] = R[(size_t)(r0 + rr) * D + r0 + jj];
+    if (jj == 0) s_fail = 0;
+    __syncthreads();
+    for (int c = 0; c < nrows; ++c) {
+        double v = 0.0;
+        if (jj >= c && jj < ncols) {
+            v = panel[c * ncols + jj];
+            for (int rr = 0; rr < c; ++rr) v -= panel[rr * ncols + jj] * panel[rr * ncols + c];
+            if (jj == c) {
+                if (!(v > 0.0) || !__builtin_isfinite(v)) {
+                    s_fail = 1;
+                } else {
+                    const double piv = __builtin_sqrt(v);
+                    panel[c * ncols + c] = piv;
+                    s_piv = piv;
+                }
+            }
+        }
+        __syncthreads();
+        if (s_fail) {
+            if (jj == 0) scal[kPsStatus] = kPooledCholeskyFailed;
+            return;
+        }
+        if (jj > c && jj < ncols) panel[c * ncols + jj] = v / s_piv;
+        __syncthreads();
+    }
+    for (int rr = 0; rr < nrows; ++rr)
+        if (jj < ncols) R[(size_t)(r0 + rr) * D + r0 + jj] = panel[rr * ncols + jj];
+}
+
+// v(c, j) -= U(r, j) * U(r, c) for the panel's rows r, in order, for every element below the panel (c >= r1, j >= c)
+__global__ void __launch_bounds__(256) chol_trailing_kernel(double* R, int D, int r0, int nrows, const double* scal) {
+    __shared__ double A[kCholPanel][kCholPanel + 1];    // U(r0 + r, c-tile)
+    __shared__ double B[kCholPanel][kCholPanel + 1];    // U(r0 + r, j-tile)
+    if (blockIdx.x < blockIdx.y) return;                // the tile lies below the diagonal
+    if (scal[kPsStatus] != kPooledOk) return;
+    const int r1 = r0 + nrows;
+    const int c0 = r1 + blockIdx.y * kCholPanel, j0 = r1 + blockIdx.x * kCholPanel;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
+    for (int rr = ty; rr < nrows; rr += 8) {
+        A[rr][tx] = (c0 + tx < D) ? R[(size_t)(r0 + rr) * D + c0 + tx] : 0.0;
+        B[rr][tx] = (j0 + tx < D) ? R[(size_t)(r0 + rr) * D + j0 + tx] : 0.0;
+    }
+    __syncthreads();
+    const int j = j0 + tx;
+    for (int cc = ty; cc < kCholPanel; cc += 8) {
+        const int c = c0 + cc;
+        if (c >= D || j >= D || j < c) continue;
+        double v = R[(size_t)c * D + j];
+        for (int rr = 0; rr < nrows; ++rr) v -= B[rr][tx] * A[rr][cc];
+        R[(size_t)c * D + j] = v;
+    }
+}
+
+__global__ void __launch_bounds__(256) chol_finish_kernel(double* R, int D, const double* scal) {
+    if (scal[kPsStatus] != kPooledOk) return;
+    const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= (size_t)D * D) return;
+    const int r = (int)(k / D), c = (int)(k % D);
+    if (c < r) R[k] = 0.0;
+}
+
+__global__ void __launch_bounds__(256) pooled_publish_kernel(const PooledPublishParams p) {
+    const int D = p.D;
+    const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t nthreads = (size_t)gridDim.x * 256;
+    // the moments of the next window are taken about the centre the running average now holds, whatever became of U
+    for (size_t d = tid; d < (size_t)D; d += nthreads) p.c0[d] = p.centre[d];
+    if (p.scal[kPsStatus] != kPooledOk) return;
+    if (p.DP > 0) {
+        const int DP = p.DP;
+        for (size_t k = tid; k < (size_t)DP * DP; k += nthreads) {
+            const int i = (int)(k / DP), j = (int)(k % DP);
+            p.U[k] = (i < D && j < D) ? p.decomp[(size_t)i * D + j] : 0.0;
+        }
+    } else {
+        const int W = p.W, CW = p.CW;
+        for (size_t k = tid; k < (size_t)W * D * CW; k += nthreads) {
+            const int jl = (int)(k % CW);
+            const int i = (int)((k / CW) % D);
+            const int w = (int)(k / ((size_t)CW * D));
+            const int j = jl * W + w;
+            p.U[k] = (j < D) ? p.decomp[(size_t)i * D + j] : 0.0;
+        }
+        if (p.nkq_padded > 0) {
+            const int ntiles = (D + 15) / 16, nkq = (D + 3) / 4, nkqp = p.nkq_padded;
+            for (size_t k = tid; k < (size_t)ntiles * nkqp * 64; k += nthreads) {
+                const int l = (int)(k % 64);
+                const int kq = (int)((k / 64) % nkqp);
+                const int jt = (int)(k / ((size_t)64 * nkqp));
+                const int i = 4 * kq + (l >> 4), j = 16 * jt + (l & 15);
+                p.Uop[k] = (kq < nkq && i < D && j < D) ? p.decomp[(size_t)i * D + j] : 0.0;
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) pooled_adjust_lanes_kernel(double* lane_f64, int npad, int nchains, const double* scal,
+                                                                   double acc_w, double acc_wW, int sigma_lane, int trials_lane) {
+    if (scal[kPsStatus] != kPooledOk) return;
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= nchains) return;
+    const double scale = scal[kPsLastScale];
+    double* sg = lane_f64 + (size_t)sigma_lane * npad + c;
+    *sg = *sg * scale;
+    if (acc_w >= 0.0) {
+        double* at = lane_f64 + (size_t)trials_lane * npad + c;
+        double t = *at;
+        t = pu_max(1.0, acc_w * t);
+        t = pu_min(t, acc_wW);
+        *at = t;
+    }
+}
+
+}  // namespace
+
+hipError_t launch_pooled_update(const PooledUpdateParams& p, hipStream_t s) {
+    const int D = p.D;
+    if (D < 1 || D > 512) return hipErrorInvalidValue;
+    const int t16 = (D + 15) / 16;
+    hipLaunchKernelGGL(pooled_absorb_kernel, dim3(t16, t16), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(pooled_scalars_kernel, dim3(1), dim3(64), 0, s, p);
+    const size_t nn = (size_t)D * D;
+    const unsigned nb = (unsigned)((nn + 255) / 256);
+    hipLaunchKernelGGL(chol_copy_kernel, dim3(nb), dim3(256), 0, s, (const double*)p.cov, p.decomp, nn, (const double*)p.scal);
+    for (int r0 = 0; r0 < D; r0 += kCholPanel) {
+        const int nrows = (D - r0 < kCholPanel) ? D - r0 : kCholPanel;
+        const size_t lds = sizeof(double) * (size_t)nrows * (size_t)(D - r0);
+        hipLaunchKernelGGL(chol_panel_kernel, dim3(1), dim3(512), lds, s, p.decomp, D, r0, p.scal);
+        const int rest = D - (r0 + nrows);
+        if (rest > 0) {
+            const int nt = (rest + kCholPanel - 1) / kCholPanel;
+            hipLaunchKernelGGL(chol_trailing_kernel, dim3(nt, nt), dim3(256), 0, s, p.decomp, D, r0, nrows, (const double*)p.scal);
+        }
+    }
+    hipLaunchKernelGGL(chol_finish_kernel, dim3(nb), dim3(256), 0, s, p.decomp, D, (const double*)p.scal);
+    return hipGetLastError();
+}
+
+// one-time: the panel kernel's dynamic LDS goes up to 128 KB
+hipError_t pooled_update_prepare() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(chol_panel_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)(sizeof(double) * kCholPanel * 512));
+}
+
+hipError_t launch_pooled_publish(const PooledPublishParams& p, hipStream_t s) {
+    hipLaunchKernelGGL(pooled_publish_kernel, dim3(256), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_pooled_adjust_lanes(double* lane_f64, int npad, int nchains, const double* scal, double acc_w, double acc_wW,
+                                      int sigma_lane, int trials_lane, hipStream_t s) {
+    hipLaunchKernelGGL(pooled_adjust_lanes_kernel, dim3((nchains + 255) / 256), dim3(256), 0, s, lane_f64, npad, nchains, scal,
+                       acc_w, acc_wW, sigma_lane, trials_lane);
+    return hipGetLastError();
+}
+
+}  // namespace smcmc

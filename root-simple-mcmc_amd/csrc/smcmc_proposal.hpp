@@ -135,6 +135,14 @@ public:
         return st;
     }
 
+    // The rest of update() after the device has done the running averages, the scalar half and found that the plain
+    // Cholesky decomposition fails (smcmc_pooled_update.hip.h): the ladder of :1134-1389 on the host.
+    UpdateStatus finishUpdateOnHost(double sigmaScale) {
+        const UpdateStatus st = decompose(false);
+        lastSigmaScale = sigmaScale;
+        return st;
+    }
+
     // Batch form of the running averages :1780-1820.  M is the packed moment
     // vector about c0 == centre: row i <= D, column j <= i, row D = {sum y_j, n}.
     void absorbMoments(const double* M, bool updateCovariance) {

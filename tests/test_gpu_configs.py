@@ -339,3 +339,82 @@ def test_native_communicator_single_rank(gpu, oracle):
     b.comm_destroy()
     with pytest.raises(gpu.SmcmcError):
         b.allreduce_moments()
+
+
+# ---------------------------------------------------------------- the pooled update on the device vs on the host
+def _ab(gpu, dim, n, kind, exact, prm=None, **params):
+    a = gpu.Engine(dim, n, likelihood=kind, likelihood_params=prm, mode=gpu.MODE_POOLED, exact=exact)
+    b = gpu.Engine(dim, n, likelihood=kind, likelihood_params=prm, mode=gpu.MODE_POOLED, exact=exact)
+    b.set_param("DEVICE_UPDATE", 0)
+    for e in (a, b):
+        for k, v in params.items():
+            e.set_param(k, v)
+    return a, b
+
+
+def _same_engines(a, b, tag):
+    assert np.array_equal(a.GetAccepted(), b.GetAccepted()), f"{tag}: points"
+    for name in ("logl", "sigma", "acceptance", "acceptance_trials", "rigidity"):
+        assert np.array_equal(a.lane(name), b.lane(name)), f"{tag}: {name}"
+    assert np.array_equal(a.covariance, b.covariance), f"{tag}: covariance"
+    assert np.array_equal(a.GetEstimatedCenter(), b.GetEstimatedCenter()), f"{tag}: centre"
+    assert np.array_equal(a.decomposition, b.decomposition), f"{tag}: decomposition"
+    for name in ("COVARIANCE_TRIALS", "CENTER_TRIALS", "SIGMA_TRACE", "COVARIANCE_TRACE", "UPDATE_COUNT", "LAST_UPDATE_PATH",
+                 "NEXT_UPDATE"):
+        assert a.get_param(name) == b.get_param(name), f"{tag}: {name}"
+
+
+@pytest.mark.parametrize("exact", [True, False])
+@pytest.mark.parametrize("dim,n", [(5, 70), (33, 128), (50, 256), (64, 64), (200, 128), (500, 64)])
+def test_device_update_is_the_host_update(gpu, dim, n, exact):
+    """SMCMC_P_DEVICE_UPDATE: running averages, sigma rescale, Cholesky (one 32-row panel at a time), operand layouts and
+    per-chain consequences on the device, without a host synchronisation, against SharedProposal on the host: same bits
+    (the host path is the one the oracle tests pin)."""
+    a, b = _ab(gpu, dim, n, 0, exact, COVARIANCE_DEWEIGHT=0.1, ACCEPTANCE_DEWEIGHT=0.2)
+    x0 = np.zeros(dim)
+    assert a.Start(x0) and b.Start(x0)
+    for w in range(4):
+        a.Step(6); b.Step(6)
+        a.sync(); b.sync()
+        if w % 2 == 1:
+            _same_engines(a, b, f"window {w}")
+    a.sync(); b.sync()                                  # nothing folded since the last one: no update on either path
+    _same_engines(a, b, "empty sync")
+    a.Step(3); b.Step(3)
+    _same_engines(a, b, "end")
+    assert a.get_param("UPDATE_COUNT") >= 5 and a.get_param("LAST_UPDATE_PATH") == 0
+
+
+@pytest.mark.parametrize("dim,n", [(6, 70), (100, 64)])
+def test_device_update_falls_back_to_the_host_ladder(gpu, dim, n):
+    """A covariance the plain Cholesky decomposition cannot take: the device raises its status word, the host runs the
+    ladder (TSimpleMCMC.H:1134-1389) from there, and the result is what the all-host update gives."""
+    a, b = _ab(gpu, dim, n, 0, True)
+    x0 = np.zeros(dim)
+    assert a.Start(x0) and b.Start(x0)
+    a.Step(4); b.Step(4)
+    a.sync(); b.sync()
+    cov = _broken_covariance(dim, 2)
+    for e in (a, b):
+        e.SetCovariance(cov)
+        e.set_param("COVARIANCE_TRIALS", 1e12)          # the folded points barely move it
+    a.Step(4); b.Step(4)
+    a.sync(); b.sync()
+    assert a.get_param("LAST_UPDATE_PATH") == 2 and b.get_param("LAST_UPDATE_PATH") == 2
+    _same_engines(a, b, "after the fallback")
+    assert np.abs(np.tril(a.decomposition, -1)).max() > 0            # an eigen-decomposition: the FULLU kernels run next
+    a.Step(5); b.Step(5)
+    a.sync(); b.sync()                                               # and the next update goes back to plain Cholesky or not,
+    _same_engines(a, b, "one window later")                          # identically
+
+
+def test_overlapped_update_changes_nothing_without_a_fallback(gpu):
+    dim, n = 50, 256
+    a, b = _ab(gpu, dim, n, 0, True)
+    b.set_param("DEVICE_UPDATE", 1)
+    b.set_param("OVERLAP_UPDATE", 1)
+    assert a.Start(np.zeros(dim)) and b.Start(np.zeros(dim))
+    for _ in range(5):
+        a.Step(8); b.Step(8)
+        a.sync(); b.sync()
+    _same_engines(a, b, "overlap vs parity mode")

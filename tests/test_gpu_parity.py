@@ -618,6 +618,11 @@ def test_restore_round_trip_of_the_pooled_engine(gpu):
     assert np.array_equal(b.GetAcceptedLogLikelihood(), a.GetAcceptedLogLikelihood())
     assert np.array_equal(b.covariance, a.covariance) and np.array_equal(b.GetEstimatedCenter(), a.GetEstimatedCenter())
     assert b.get_param("TOTAL_STEPS") == 200 and np.all(b.lane("trials") == st["trials"])
+    # what is saved is what the reference would hold after the update: sigma already rescaled by sqrt(trace0 / trace)
+    # (TSimpleMCMC.H:1042-1043), next to the trace it was rescaled to -- and that is what a restored chain starts from
+    assert st["sigma"] == a.lane("sigma")[5] and st["acceptance_trials"] == a.lane("acceptance_trials")[5]
+    assert a.get_param("SIGMA_TRACE") == a.get_param("COVARIANCE_TRACE")
+    assert np.all(b.lane("sigma") == st["sigma"]) and b.get_param("SIGMA_TRACE") == a.get_param("SIGMA_TRACE")
     b.Step(20); b.sync()
     assert np.isfinite(b.GetAcceptedLogLikelihood()).all()
 

@@ -114,6 +114,7 @@ struct smcmc_engine {
     double *d_centre = nullptr, *d_cov = nullptr, *d_decomp = nullptr, *d_scal = nullptr;
     double* h_scal = nullptr;      // pinned: the scalars (status word included) of the latest device update
     hipEvent_t status_event = nullptr;
+    bool update_prepared = false;  // pooled_update_prepare() has run on this engine's device
     bool status_pending = false;   // a device update whose status the host has not looked at yet
     bool host_stale = false;       // the device holds newer centre / covariance / decomposition / trials than *prop
     bool device_stale = true;      // *prop was changed on the host since the device copy was written
@@ -536,8 +537,11 @@ int device_apply(smcmc_engine* h) {
         st = push_shared(h);
         if (st) return st;
     }
-    static const hipError_t prepared = pooled_update_prepare();
-    if (prepared != hipSuccess) return fail(h, SMCMC_ERR_HIP, std::string("pooled update setup: ") + hipGetErrorString(prepared));
+    if (!h->update_prepared) {   // per engine, i.e. per device: the panel kernel's dynamic LDS limit
+        const hipError_t prepared = pooled_update_prepare();
+        if (prepared != hipSuccess) return fail(h, SMCMC_ERR_HIP, std::string("pooled update setup: ") + hipGetErrorString(prepared));
+        h->update_prepared = true;
+    }
     PooledUpdateParams u;
     u.D = h->dim; u.M = h->d_moments; u.centre = h->d_centre; u.cov = h->d_cov; u.decomp = h->d_decomp; u.scal = h->d_scal;
     u.cov_window = P.covWindow; u.cov_deweight = P.covDeweight;

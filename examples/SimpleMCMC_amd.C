@@ -39,11 +39,16 @@ int SimpleMCMC(int cycles, int steps, const char* outputName, int dim, int chain
     std::cout << "Simple MCMC (MI355X engine) D=" << dim << " chains=" << chains << std::endl;
     sMCMC::TreeType tree("SimpleMCMC", "Tree of accepted points");
     // the likelihood is chosen at compile time, as SimpleMCMC.C:5-39 does: the README's isotropic Gaussian by
-    // default, -DUSE_HEADER_TDUMMY for the quadratic form of TDummyLogLikelihood.H, -DUSE_HARD_LIKELIHOOD for Rosenbrock
+    // default, -DUSE_HEADER_TDUMMY for the quadratic form of TDummyLogLikelihood.H, -DUSE_HARD_LIKELIHOOD for Rosenbrock,
+    // -DUSE_ASYM_LIKELIHOOD / -DUSE_HORRIFIC_LIKELIHOOD for the two stress targets (SimpleMCMC.C:5-30)
 #if defined(USE_HEADER_TDUMMY)
     typedef sMCMC::TDummyLogLikelihood Likelihood;
 #elif defined(USE_HARD_LIKELIHOOD)
     typedef sMCMC::THardLogLikelihood Likelihood;
+#elif defined(USE_ASYM_LIKELIHOOD)
+    typedef sMCMC::TASymLogLikelihood Likelihood;
+#elif defined(USE_HORRIFIC_LIKELIHOOD)
+    typedef sMCMC::THorrificLogLikelihood Likelihood;
 #else
     typedef sMCMC::TIsoGaussLogLikelihood Likelihood;
 #endif

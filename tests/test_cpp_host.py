@@ -312,3 +312,61 @@ def test_vaat_example_is_the_reference_chain(gpu, oracle, tmp_path):
         assert np.array_equal(x, o.x[:, 0]), f"entry {k}"
         assert float(row[col["LogLikelihood"]]) == o.lane("logl")[0]
         assert float(row[col["StepRMS"]]) == o.lane("step_rms")[0]
+
+
+def _build_example(tmp_path, source, *defines):
+    exe = str(tmp_path / (os.path.splitext(source)[0] + "".join(d.replace("-D", "_") for d in defines) + ".exe"))
+    cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-Werror", f"-I{os.path.join(ROOT, 'include')}", *defines,
+           os.path.join(ROOT, "examples", source), f"-L{LIBDIR}", "-lsmcmc_amd",
+           f"-Wl,-rpath,{LIBDIR}", "-Wl,-rpath,/opt/rocm/lib", "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return exe
+
+
+def test_every_likelihood_switch_of_the_example_compiles(smcmc, tmp_path):
+    """SimpleMCMC.C:5-39 picks its likelihood with a macro; so does the example."""
+    for define in ("-DUSE_HEADER_TDUMMY", "-DUSE_HARD_LIKELIHOOD", "-DUSE_ASYM_LIKELIHOOD", "-DUSE_HORRIFIC_LIKELIHOOD"):
+        _build_example(tmp_path, "SimpleMCMC_amd.C", define)
+    _build_example(tmp_path, "Constrained_amd.C")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("define,dim", [("-DUSE_ASYM_LIKELIHOOD", 100), ("-DUSE_HORRIFIC_LIKELIHOOD", 75)])
+def test_example_runs_the_stress_likelihoods(gpu, tmp_path, define, dim):
+    exe = _build_example(tmp_path, "SimpleMCMC_amd.C", define)
+    out = tmp_path / "stress.csv"
+    r = subprocess.run([exe, "1", "200", str(out), str(dim), "64"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = open(out).read().splitlines()
+    col = {h: i for i, h in enumerate(lines[0].split(",")) if h}
+    logl = np.array([float(l.split(",")[col["LogLikelihood"]]) for l in lines[1:]])
+    assert np.all(np.isfinite(logl)) and np.all(logl > -1E+29)        # never an accepted point outside the unit box
+    assert len(np.unique(logl)) >= 2                                  # the chain moves (the macro saves per cycle, not per step)
+
+
+@pytest.mark.gpu
+def test_constrained_example_recovers_the_closed_form_posterior(gpu, oracle, tmp_path):
+    """example4/Constrained.C on the engine: the tree of chain 0 (after the macro's two burn-in legs) sits on the
+    Gaussian with precision diag(1/s_i^2) + 1 1^T / 16^2."""
+    exe = _build_example(tmp_path, "Constrained_amd.C")
+    out = tmp_path / "constrained.csv"
+    trials = 30000
+    r = subprocess.run([exe, str(trials), str(out), "256"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("Finished burnin chain") == 2
+    lines = open(out).read().splitlines()
+    header = lines[0].split(",")
+    col = {h: i for i, h in enumerate(header) if h}
+    rows = [l.split(",") for l in lines[1:]]
+    assert len(rows) == trials
+    x = np.array([[float(r_[col[f"Accepted[{d}]"]]) for d in range(25)] for r_ in rows[::10]])
+    prm = oracle.constrained_params(25)
+    S, c, mu, s = prm[0], prm[1], prm[2:27], prm[27:]
+    cov = np.linalg.inv(np.diag(1.0 / s ** 2) + np.ones((25, 25)) / c ** 2)
+    mean = cov @ (mu / s ** 2 + S / c ** 2)
+    sd = np.sqrt(np.diag(cov))
+    # one chain, 30 000 correlated steps (acceptance ~0.23 in 25 dimensions): a loose band is all a single chain gives
+    assert np.all(np.abs(x.mean(axis=0) - mean) < 1.0 * sd), np.max(np.abs(x.mean(axis=0) - mean) / sd)
+    assert np.all(np.abs(x.std(axis=0) / sd - 1.0) < 0.5)
+    assert abs(x.sum(axis=1).mean() - mean.sum()) < 0.5 * np.sqrt(np.ones(25) @ cov @ np.ones(25))

@@ -526,6 +526,10 @@ class HmcEnsemble:
         self._config = [alpha, int(potential_from_gradient), int(fused_gradient), int(gradient_type)]
         lib().oracle_hmc_ensemble_configure(self._h, *self._config)
 
+    def set_alpha(self, a):
+        self._config[0] = float(a)
+        lib().oracle_hmc_ensemble_configure(self._h, *self._config)
+
     def set_gradient_type(self, t):
         """Step(save, gradientType) for the steps that follow (TSimpleHMC.H:279, 467-532)."""
         self._config[3] = int(t)

@@ -370,3 +370,28 @@ def test_constrained_example_recovers_the_closed_form_posterior(gpu, oracle, tmp
     assert np.all(np.abs(x.mean(axis=0) - mean) < 1.0 * sd), np.max(np.abs(x.mean(axis=0) - mean) / sd)
     assert np.all(np.abs(x.std(axis=0) / sd - 1.0) < 0.5)
     assert abs(x.sum(axis=1).mean() - mean.sum()) < 0.5 * np.sqrt(np.ones(25) @ cov @ np.ones(25))
+
+
+def test_ahmc_example_compiles(smcmc, tmp_path):
+    _build_example(tmp_path, "SimpleAHMC_amd.C")
+
+
+@pytest.mark.gpu
+def test_ahmc_example_runs_the_three_phases(gpu, tmp_path):
+    """SimpleAHMC.C's schedule on TSimpleHMC_amd.H: Step(false, 5) with SetLeapFrog(0), then Step(., 2) with five leapfrog
+    steps: the gradient count is exactly six per step of the last two phases, none in the first."""
+    exe = _build_example(tmp_path, "SimpleAHMC_amd.C")
+    out = tmp_path / "ahmc.csv"
+    dim, trials = 8, 300
+    r = subprocess.run([exe, str(trials), str(out), str(dim), "64"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    burnin = 500 + 2 * dim * dim
+    assert f"and {(burnin + trials) * 6} gradients" in r.stdout
+    assert "Start burn-in" in r.stdout and "Second burn-in" in r.stdout and "Run chain" in r.stdout
+    lines = open(out).read().splitlines()
+    col = {h: i for i, h in enumerate(lines[0].split(",")) if h}
+    rows = [l.split(",") for l in lines[1:]]
+    assert len(rows) == trials + 1                                   # Start(p, true) + the saved run
+    assert int(rows[-1][col["Steps"]]) == 2 * burnin + trials
+    x = np.array([[float(r_[col[f"Accepted[{d}]"]]) for d in range(dim)] for r_ in rows[1:]])
+    assert np.all(np.isfinite(x)) and len(np.unique(x[:, 1])) > trials // 10     # the covariant gradient moves the chain

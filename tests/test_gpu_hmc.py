@@ -285,3 +285,31 @@ def test_hmc_gradient_types_need_reference_order(gpu):
     assert err.value.status == 5   # SMCMC_ERR_UNSUPPORTED
     with pytest.raises(gpu.SmcmcError):
         e.SetGradientType(6)
+
+
+@pytest.mark.parametrize("kind,dim", [(0, 6), (1, 20), (1, 100)])
+def test_hmc_approximate_gradient_schedule(gpu, oracle, kind, dim):
+    """SimpleAHMC.C:45-92's three phases: a random walk with the momentum kept (alpha 0.8, SetLeapFrog(0), gradient type 5)
+    that only feeds the running covariance, then the covariant gradient (type 2) from that covariance."""
+    n = 64
+    prm = np.linalg.inv(_spd(dim, 21)) if kind == 1 else None
+    e, o = _adaptive_pair(gpu, oracle, dim, n, kind, prm, True, 1)
+    e.TrackCovariance()
+    rng = np.random.default_rng(dim)
+    x0 = rng.uniform(-1.0, 1.0, size=dim)                            # SimpleAHMC.C:43
+    e.Start(x0); o.start(x0)
+    e.SetAlpha(0.8); o.set_alpha(0.8)                                # :52-54
+    e.SetMeanEpsilon(-0.1); o.set_mean_epsilon(-0.1)
+    e.SetLeapFrog(0); o.set_leapfrog(0)
+    e.Step(40, gradient_type=5); o.set_gradient_type(5); o.step(40)
+    _same_hmc(e, o, "first burn-in")
+    assert e.tuning["updates"] == 0 and e.tuning["cov_trials"] > 0   # SetLeapFrog(0): UpdateErrorMatrix returns at once (:704)
+    e.SetAlpha(0.0); o.set_alpha(0.0)                                # :68-70
+    e.SetMeanEpsilon(-0.05); o.set_mean_epsilon(-0.05)
+    e.SetLeapFrog(5); o.set_leapfrog(5)
+    e.Step(3 * dim + 10, gradient_type=2); o.set_gradient_type(2); o.step(3 * dim + 10)
+    _same_hmc(e, o, "second burn-in")
+    e.SetAlpha(0.75); o.set_alpha(0.75)                              # :86-88
+    e.Step(20, gradient_type=2); o.step(20)
+    _same_hmc(e, o, "run")
+    assert e.lane("naccept").sum() > 0

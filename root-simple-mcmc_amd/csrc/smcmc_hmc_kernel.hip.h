@@ -405,6 +405,9 @@ __global__ void __launch_bounds__(W * kWave) hmc_step_kernel(const HmcParams p) 
         // the largest one, a chain takes its last (half) kick at its own count and then stands still. ----
         const int L = active ? (lfrog < 0 ? -lfrog : lfrog) : 0;
         const int Lmax = wave_max_i32(L);
+        // the reversal test only reaches a chain whose leapfrog count is automatic (hmc_retune_after_leapfrog): with every
+        // count of the group fixed its gathers are skipped (lane = chain in every wavefront: workgroup-uniform)
+        const bool reversal_wanted = p.adaptive && wave_max_i32((active && lfrog > 0) ? 1 : 0) != 0;
         int status = 1;                                                        // leapStatus
         if (Lmax < 1) {
             // the one-step shortcut (:598-611): qNew += eps*(momentum + pNew)/2 with pNew == momentum
@@ -449,7 +452,7 @@ __global__ void __launch_bounds__(W * kWave) hmc_step_kernel(const HmcParams p) 
                         p.pn[(size_t)i * NP + chain] = last ? m - eps * gr[il] / 2.0 : m - eps * gr[il];
                     }
                 }
-                if (p.adaptive && ls < Lmax - 1) {
+                if (reversal_wanted && ls < Lmax - 1) {
                     // has the direction reversed (:633-638)?  Only the automatic leapfrog count listens.
                     __syncthreads();
                     double inner = 0.0;

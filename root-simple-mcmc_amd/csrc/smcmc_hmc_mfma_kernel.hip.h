@@ -246,6 +246,7 @@ __global__ void __launch_bounds__(kMfW* kWave, 1) hmc_mfma_kernel(const HmcParam
         const double mix = __builtin_sqrt(1.0 - p.alpha * p.alpha);
         double eps[2];
         int Lc[2];   // leapfrog count of this lane's two chains
+        int automatic = 0;   // some chain of the workgroup keeps an automatic leapfrog count (fLeapFrogSteps > 0)
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
             const uint32_t gid = p.chain_offset + (uint32_t)(base + 16 * ct + c);
@@ -255,6 +256,7 @@ __global__ void __launch_bounds__(kMfW* kWave, 1) hmc_mfma_kernel(const HmcParam
                 abs_eps = __builtin_fabs(p.lane_f64[kHmcLaneMeanEpsilon * NP + base + 16 * ct + c]);
                 const int l = p.lane_i32[kHmcLaneLeapfrog * NP + base + 16 * ct + c];
                 Lc[ct] = (base + 16 * ct + c < p.nchains) ? (l < 0 ? -l : l) : 0;
+                automatic |= (l > 0) ? 1 : 0;
             }
 #pragma unroll
             for (int t = 0; t < kMfTI; ++t)
@@ -290,6 +292,10 @@ __global__ void __launch_bounds__(kMfW* kWave, 1) hmc_mfma_kernel(const HmcParam
         // ---- LeapFrog (:582-651).  Chains of the workgroup may differ in their leapfrog count: the workgroup runs to
         // the largest one, a chain takes its last (half) kick at its own count and then stands still. ----
         const int Lmax = wave_max_i32(Lc[0] > Lc[1] ? Lc[0] : Lc[1]);
+        // the reversal test (:633-638) only ever reaches a chain through hmc_retune_after_leapfrog, which listens when the
+        // chain's count is automatic: with every count fixed (SetLeapFrog) its 500-term ordered sums are skipped.
+        // Every wavefront of the workgroup holds the same 32 chains, so a wavefront-wide test is workgroup-uniform.
+        const bool reversal_wanted = p.adaptive && wave_max_i32(automatic) != 0;
         const int Lmine = lfrog < 0 ? -lfrog : lfrog;                   // summing lanes: their chain's count
         int status = 1;                                                 // leapStatus of the summing lane's chain
         // iteration ls of a chain with L steps: ls < L - 1 the body of :623-639, ls == L - 1 the last position step
@@ -344,7 +350,7 @@ __global__ void __launch_bounds__(kMfW* kWave, 1) hmc_mfma_kernel(const HmcParam
                 drift(ls);
                 gradient();
                 kick(ls);
-                if (p.adaptive && ls < Lmax - 1) {
+                if (reversal_wanted && ls < Lmax - 1) {
                     // has the direction reversed (:633-638)?  inner += pNew[j]*momentum[j], dimension order; the
                     // starting momentum was parked in p.pn
                     const double inner = ordered_sum_tiles([&](int t, int ct, int r) {

@@ -204,7 +204,7 @@ size_t npacked(const smcmc_engine* h) { return (size_t)(h->dim + 1) * (h->dim + 
 size_t gacc_doubles(const smcmc_engine* h) {
     if (h->panel_w) {
         const size_t T = (size_t)(h->dim + 1 + 15) / 16;
-        return (size_t)kFoldSlices * (T * (T + 1) / 2) * 4 * kWave;
+        return (size_t)fold_slices(h->dim) * (T * (T + 1) / 2) * 4 * kWave;
     }
     return (size_t)h->ngroups * h->nt * 4 * kWave;
 }

@@ -4,9 +4,10 @@
 // wavefront's registers, so the fold of the current point into the moment sums
 // (the batch form of the running covariance, reference TSimpleMCMC.H:1795-1820)
 // runs as its own kernel between step launches: one wavefront per (4 x 4 block of
-// 16x16 output tiles, chain slice), y = x - c0 from the [dim][chain] state (staged
-// through LDS in full cache lines), chains of the slice folded in ascending order by
-// chains of v_mfma_f64_16x16x4_f64.
+// 16x16 output tiles, chain slice), four such wavefronts (a 2 x 2 arrangement of blocks)
+// sharing the operand tiles their workgroup stages, y = x - c0 from the [dim][chain]
+// state (staged through LDS in 256-byte runs), chains of the slice folded in ascending
+// order by chains of v_mfma_f64_16x16x4_f64.
 // The accumulators persist in HBM across folds; the slice sums are added in slice
 // order by fold_reduce_kernel.  oracle/ensemble_oracle.c mirrors this order with
 // moment groups of `slice_chains` chains.
@@ -19,57 +20,73 @@
 
 namespace smcmc {
 
-constexpr int kFoldSlices = 32;   // most chain slices (moment groups) of the large-dimension path
-// Slices actually used: as many as give every SIMD of the 256 CUs at most one wavefront (blocks x slices <=
-// 1024), a multiple of the workgroup's wavefronts, so that a fold is one round of workgroups with no tail.
+constexpr int kFoldSlices = 128;  // most chain slices (moment groups) of the large-dimension path (32 until round 2: at
+                                  // D = 200 that left two thirds of the SIMDs without a wavefront)
+constexpr int kFoldBT = 4;        // a wavefront folds a block of kFoldBT x kFoldBT tiles (64 x 64 moments)
+constexpr int kFoldSB = 2;        // a workgroup folds kFoldSB x kFoldSB such blocks of the same chain slice
+constexpr int kFoldWaves = kFoldSB * kFoldSB;
+constexpr int kFoldOps = 2 * kFoldSB * kFoldBT;   // operand tiles a workgroup stages: its row group and its column group
+
+// super-blocks (workgroups per slice): the lower triangle of the kFoldSB * kFoldBT-tile grid
+inline int fold_super_blocks(int D) {
+    const int T = (D + 1 + 15) / 16, TB = (T + kFoldBT - 1) / kFoldBT, SB = (TB + kFoldSB - 1) / kFoldSB;
+    return SB * (SB + 1) / 2;
+}
+// Slices actually used: as many as give every CU at most one workgroup (one wavefront per SIMD), so that a fold is
+// one round of workgroups with no tail.
 inline int fold_slices(int D) {
-    const int T = (D + 1 + 15) / 16, TB = (T + 3) / 4, nblocks = TB * (TB + 1) / 2;
-    int n = 4 * (256 / nblocks);
+    int n = 256 / fold_super_blocks(D);
     if (n > kFoldSlices) n = kFoldSlices;
-    if (n < 4) n = 4;
+    if (n < 1) n = 1;
     return n;
 }
-constexpr int kFoldBT = 4;        // a wavefront folds a block of kFoldBT x kFoldBT tiles (64 x 64 moments)
 
-// grid = (nblocks, nslices / 4), block = 256.  block -> (bi, bj <= bi) of 4 x 4 tiles: eight operand
-// tiles feed sixteen matrix instructions.  The state is read in full cache lines (lane -> row
-// lane >> 2, four consecutive chains), one stage of 16 chains ahead of its use, and re-laid out
-// through LDS into the operand layout (row lane & 15, chain 4 n + (lane >> 4)).
-// Four wavefronts per workgroup (four slices of the same block) and more than half of a CU's LDS per
-// workgroup: one workgroup per CU, one wavefront per SIMD -- single-wavefront workgroups stack up on a
-// few CUs instead and leave the rest idle.
-constexpr int kFoldWaves = 4;
+// grid = (super-blocks, slices), block = 256.  Wavefront (a2, b2) of the workgroup owns block (2 BI + a2, 2 BJ + b2) of
+// 4 x 4 tiles: eight operand tiles feed its sixteen matrix instructions per four chains.  The workgroup stages the
+// sixteen operand tiles of its row group and column group once for all four wavefronts (round 1 staged eight tiles per
+// wavefront and read the state nine times over at D = 500: 1.2 GB per fold, which bound it; now 0.6 GB).  The state is
+// read in full cache lines (lane -> row lane >> 2, four consecutive chains), one stage of 16 chains ahead of its use,
+// and re-laid out through LDS into the operand layout (row lane & 15, chain 4 n + (lane >> 4)).
 // mask (optional, [npad]): a chain with mask 0 folds nothing this time (the HMC engine: a step whose proposal had a
 // non-finite potential skips UpdateCovariance, TSimpleHMC.H:336)
 static __global__ void __launch_bounds__(kFoldWaves* kWave) fold_moments_kernel(const double* __restrict__ x, const double* __restrict__ c0,
                                                              int nchains, int npad, int D, int slice_chains,
                                                              double* __restrict__ gacc, const int32_t* __restrict__ mask) {
-    constexpr int kS = 18;   // doubles per staged row: 16 chains + 2 (operand reads spread over the banks)
-    __shared__ __attribute__((aligned(16))) double st_all[kFoldWaves][2 * kFoldBT][16][kS];
-    __shared__ double occupancy_pad[1100];   // pushes the workgroup past 80 KB of LDS: one workgroup per CU
+    constexpr int kC = 32;        // chains per stage: 256 contiguous bytes of every staged row (16 chains = 128-byte
+                                  // pieces of 64 000 concurrent row streams ran the memory system at a fifth of its rate;
+                                  // 64 chains per stage measured no better than 32)
+    constexpr int kS = kC + 2;    // doubles per staged row: the chains + 2 (operand reads spread over the banks)
+    constexpr int kL = kC / 8;    // 16-byte loads per lane and operand tile (a lane holds kC / 4 consecutive chains of one row)
+    __shared__ __attribute__((aligned(16))) double st[kFoldOps][16][kS];
     const int lane = threadIdx.x & (kWave - 1);
     const int wv = threadIdx.x / kWave;
-    if (threadIdx.x == 0 && D < 0) occupancy_pad[0] = 0.0;   // keeps the array (never true)
-    double (*st)[16][kS] = st_all[wv];
-    const int slice = blockIdx.y * kFoldWaves + wv;
-    const int T = (D + 1 + 15) / 16, ntiles = T * (T + 1) / 2;
-    int bi = 0;
-    while ((bi + 1) * (bi + 2) / 2 <= (int)blockIdx.x) ++bi;
-    const int bj = (int)blockIdx.x - bi * (bi + 1) / 2;
+    const int slice = blockIdx.y;
+    const int T = (D + 1 + 15) / 16, ntiles = T * (T + 1) / 2, TB = (T + kFoldBT - 1) / kFoldBT;
+    int BI = 0;
+    while ((BI + 1) * (BI + 2) / 2 <= (int)blockIdx.x) ++BI;
+    const int BJ = (int)blockIdx.x - BI * (BI + 1) / 2;
+    const bool sdiag = (BI == BJ);                      // the column group is the row group
+    const int a2 = wv / kFoldSB, b2 = wv % kFoldSB;
+    const int bi = kFoldSB * BI + a2, bj = kFoldSB * BJ + b2;
+    const bool mine = bi < TB && bj <= bi;              // this wavefront has a block (it stages its share either way)
     const bool diagonal = (bi == bj);
+    const int nops = sdiag ? kFoldSB * kFoldBT : kFoldOps;
+    const int colbase = sdiag ? 0 : kFoldSB * kFoldBT;  // first staged tile of the column group
     const size_t NP = (size_t)npad;
-    // staging role of this lane: row (lane >> 2) of every operand tile, chains 4 (lane & 3) .. + 3
+    // staging role of this lane: row (lane >> 2) of the wavefront's share of the operand tiles, kC / 4 consecutive chains
     const int srow = lane >> 2, sq = lane & 3;
-    int rr[2 * kFoldBT];
-    double cc[2 * kFoldBT];
+    constexpr int kShare = kFoldOps / kFoldWaves;       // operand tiles a wavefront fetches per stage
+    int rr[kShare];
+    double cc[kShare];
 #pragma unroll
-    for (int op = 0; op < 2 * kFoldBT; ++op) {
-        const int tile = (op < kFoldBT) ? kFoldBT * bi + op : kFoldBT * bj + (op - kFoldBT);
-        rr[op] = 16 * tile + srow;
-        cc[op] = (rr[op] < D) ? c0[rr[op]] : 0.0;
+    for (int q = 0; q < kShare; ++q) {
+        const int op = wv + kFoldWaves * q;
+        const int tile = (op < kFoldSB * kFoldBT) ? kFoldSB * kFoldBT * BI + op : kFoldSB * kFoldBT * BJ + (op - kFoldSB * kFoldBT);
+        rr[q] = 16 * tile + srow;
+        cc[q] = (rr[q] < D) ? c0[rr[q]] : 0.0;
     }
     // tile (ti, tj) of the block: valid when it exists and lies in the lower triangle
-    auto valid = [&](int a, int b) { return kFoldBT * bi + a < T && kFoldBT * bj + b <= kFoldBT * bi + a; };
+    auto valid = [&](int a, int b) { return mine && kFoldBT * bi + a < T && kFoldBT * bj + b <= kFoldBT * bi + a; };
     auto offset = [&](int a, int b) {
         const int ti = kFoldBT * bi + a, tj = kFoldBT * bj + b;
         return (((size_t)slice * ntiles + (size_t)(ti * (ti + 1) / 2 + tj)) * 4) * kWave + lane;
@@ -83,61 +100,53 @@ static __global__ void __launch_bounds__(kFoldWaves* kWave) fold_moments_kernel(
             for (int r = 0; r < 4; ++r) acc[a][b][r] = valid(a, b) ? gacc[offset(a, b) + (size_t)r * kWave] : 0.0;
     const int c_begin = slice * slice_chains;
     const int c_end = (c_begin + slice_chains < npad) ? c_begin + slice_chains : npad;
-    const int nops = diagonal ? kFoldBT : 2 * kFoldBT;   // a diagonal block's column operands are its row operands
 
-    typedef f64x2 stage_t[2 * kFoldBT][2];
-    stage_t stA, stB;   // two stages of 16 chains in flight ahead of the matrix instructions
+    typedef f64x2 stage_t[kShare][kL];
+    stage_t stA, stB;   // two stages of kC chains in flight ahead of the matrix instructions
     auto fetch = [&](int c, stage_t& stage) {   // y = x - c0 (the constant 1 in row D, 0 above, 0 for chains past the ensemble)
-        const int chain = c + 4 * sq;
-        bool on[4];
+        const int chain = c + 2 * kL * sq;
+        bool on[2 * kL];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) on[k] = (chain + k < nchains) && (mask == nullptr || mask[chain + k] != 0);
+        for (int k = 0; k < 2 * kL; ++k) on[k] = (chain + k < nchains) && (mask == nullptr || mask[chain + k] != 0);
 #pragma unroll
-        for (int op = 0; op < 2 * kFoldBT; ++op) {
-            if (op >= nops) continue;
-            f64x2 v0 = {0.0, 0.0}, v1 = {0.0, 0.0};
-            if (rr[op] < D) {
-                const f64x2* src = (const f64x2*)(x + (size_t)rr[op] * NP + chain);
-                v0 = src[0];
-                v1 = src[1];
-                v0[0] -= cc[op]; v0[1] -= cc[op]; v1[0] -= cc[op]; v1[1] -= cc[op];
-            } else if (rr[op] == D) {
-                v0[0] = v0[1] = v1[0] = v1[1] = 1.0;
+        for (int q = 0; q < kShare; ++q) {
+            if (wv + kFoldWaves * q >= nops) continue;
+#pragma unroll
+            for (int k = 0; k < kL; ++k) {
+                f64x2 v = {0.0, 0.0};
+                if (rr[q] < D) {
+                    v = ((const f64x2*)(x + (size_t)rr[q] * NP + chain))[k];
+                    v[0] -= cc[q]; v[1] -= cc[q];
+                } else if (rr[q] == D) {
+                    v[0] = v[1] = 1.0;
+                }
+                if (!on[2 * k]) v[0] = 0.0;
+                if (!on[2 * k + 1]) v[1] = 0.0;
+                stage[q][k] = v;
             }
-            if (!on[0]) v0[0] = 0.0;
-            if (!on[1]) v0[1] = 0.0;
-            if (!on[2]) v1[0] = 0.0;
-            if (!on[3]) v1[1] = 0.0;
-            stage[op][0] = v0;
-            stage[op][1] = v1;
         }
     };
-    // one stage: registers -> LDS, refill the registers two stages ahead, fold the 16 chains
-    // Every wavefront stages through its own LDS region (st_all[wv]) and the slices of a workgroup can differ in
-    // length, so the hand-over is ordered within the wavefront only: LDS operations of one wavefront complete in
-    // issue order, the fences keep the compiler from moving them across.
-    auto wave_lds_sync = [] {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    };
+    // one stage: registers -> LDS (every wavefront its share), refill the registers two stages ahead, fold the 16 chains.
+    // All wavefronts of the workgroup walk the same slice, so the barriers are uniform.
     auto consume = [&](int c, stage_t& stage) {
-        wave_lds_sync();   // the previous stage has been consumed
+        __syncthreads();   // the previous stage has been consumed by every wavefront
 #pragma unroll
-        for (int op = 0; op < 2 * kFoldBT; ++op) {
+        for (int q = 0; q < kShare; ++q) {
+            const int op = wv + kFoldWaves * q;
             if (op >= nops) continue;
-            *(f64x2*)&st[op][srow][4 * sq] = stage[op][0];
-            *(f64x2*)&st[op][srow][4 * sq + 2] = stage[op][1];
-        }
-        wave_lds_sync();
-        if (c + 32 < c_end) fetch(c + 32, stage);   // in flight under the matrix instructions
 #pragma unroll
-        for (int n = 0; n < 4; ++n) {
+            for (int k = 0; k < kL; ++k) *(f64x2*)&st[op][srow][2 * kL * sq + 2 * k] = stage[q][k];
+        }
+        __syncthreads();
+        if (c + 2 * kC < c_end) fetch(c + 2 * kC, stage);   // in flight under the matrix instructions
+        if (!mine) return;
+#pragma unroll
+        for (int n = 0; n < kC / 4; ++n) {
             double av[kFoldBT], bv[kFoldBT];
 #pragma unroll
             for (int a = 0; a < kFoldBT; ++a) {
-                av[a] = st[a][lane & 15][4 * n + (lane >> 4)];
-                bv[a] = diagonal ? av[a] : st[kFoldBT + a][lane & 15][4 * n + (lane >> 4)];
+                av[a] = st[kFoldBT * a2 + a][lane & 15][4 * n + (lane >> 4)];
+                bv[a] = diagonal ? av[a] : st[colbase + kFoldBT * b2 + a][lane & 15][4 * n + (lane >> 4)];
             }
 #pragma unroll
             for (int a = 0; a < kFoldBT; ++a)
@@ -147,10 +156,10 @@ static __global__ void __launch_bounds__(kFoldWaves* kWave) fold_moments_kernel(
         }
     };
     if (c_begin < c_end) fetch(c_begin, stA);
-    if (c_begin + 16 < c_end) fetch(c_begin + 16, stB);
-    for (int c = c_begin; c < c_end; c += 32) {
+    if (c_begin + kC < c_end) fetch(c_begin + kC, stB);
+    for (int c = c_begin; c < c_end; c += 2 * kC) {
         consume(c, stA);
-        if (c + 16 < c_end) consume(c + 16, stB);
+        if (c + kC < c_end) consume(c + kC, stB);
     }
 #pragma unroll
     for (int a = 0; a < kFoldBT; ++a)

@@ -87,7 +87,7 @@ struct HmcDeviceGuard {
 size_t hmc_npacked(const smcmc_hmc* h) { return (size_t)(h->dim + 1) * (h->dim + 2) / 2; }
 size_t hmc_gacc_doubles(const smcmc_hmc* h) {
     const size_t T = (size_t)(h->dim + 1 + 15) / 16;
-    return (size_t)kFoldSlices * (T * (T + 1) / 2) * 4 * kWave;
+    return (size_t)fold_slices(h->dim) * (T * (T + 1) / 2) * 4 * kWave;
 }
 
 // the chains retune themselves (TSimpleHMC.H:302-345, 833-847) unless both the step length and the count are fixed

@@ -43,9 +43,8 @@ hipError_t launch_panel<SMCMC_PANEL_W, kPanelCW>(const PanelParams& p, int like,
 #if SMCMC_PANEL_W == 4
 hipError_t launch_fold(const double* x, const double* c0, int nchains, int npad, int D, int slice_chains, int nslices,
                        double* gacc, hipStream_t s, const int32_t* mask) {
-    const int T = (D + 1 + 15) / 16, TB = (T + kFoldBT - 1) / kFoldBT, nblocks = TB * (TB + 1) / 2;
-    if (nslices < kFoldWaves || nslices % kFoldWaves != 0 || nslices > kFoldSlices) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(fold_moments_kernel, dim3(nblocks, nslices / kFoldWaves), dim3(kFoldWaves * kWave), 0, s, x, c0,
+    if (nslices < 1 || nslices > kFoldSlices) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(fold_moments_kernel, dim3(fold_super_blocks(D), nslices), dim3(kFoldWaves * kWave), 0, s, x, c0,
                        nchains, npad, D, slice_chains, gacc, mask);
     return hipGetLastError();
 }

@@ -545,19 +545,20 @@ int device_apply(smcmc_engine* h) {
     PooledUpdateParams u;
     u.D = h->dim; u.M = h->d_moments; u.centre = h->d_centre; u.cov = h->d_cov; u.decomp = h->d_decomp; u.scal = h->d_scal;
     u.cov_window = P.covWindow; u.cov_deweight = P.covDeweight;
-    hipError_t e = launch_pooled_update(u, h->stream);
-    if (e != hipSuccess) return fail(h, SMCMC_ERR_HIP, std::string("pooled update launch: ") + hipGetErrorString(e));
     PooledPublishParams q;
     std::memset(&q, 0, sizeof(q));
     q.D = h->dim; q.decomp = h->d_decomp; q.centre = h->d_centre; q.scal = h->d_scal; q.U = h->d_U; q.c0 = h->d_c0;
+    hipError_t e;
     if (h->panel_w) {
         q.W = h->panel_w; q.CW = kPanelCW;
         if (!h->exact) { q.Uop = h->d_Uop; q.nkq_padded = panel_mfma_nkq_padded(h->dim); }
+        e = launch_pooled_update(u, h->stream);
+        if (e == hipSuccess) e = launch_pooled_publish(q, h->stream);
     } else {
         q.DP = h->dp;
+        e = launch_pooled_small_update(u, q, h->stream);   // dim <= 63: one single-workgroup kernel
     }
-    e = launch_pooled_publish(q, h->stream);
-    if (e != hipSuccess) return fail(h, SMCMC_ERR_HIP, std::string("publish launch: ") + hipGetErrorString(e));
+    if (e != hipSuccess) return fail(h, SMCMC_ERR_HIP, std::string("pooled update launch: ") + hipGetErrorString(e));
     // the host-only half of SharedProposal::update, optimistically (check_pending takes it back if the device says no)
     h->before_update = {P.updateCount, P.nextUpdate, P.lastPath, P.acceptanceTrials, P.decompFull};
     ++P.updateCount;

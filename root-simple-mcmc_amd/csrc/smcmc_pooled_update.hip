@@ -205,7 +205,125 @@ __global__ void __launch_bounds__(256) pooled_adjust_lanes_kernel(double* lane_f
     }
 }
 
+// dim <= 64: the whole update in one workgroup -- absorb, scalar half, Cholesky (the matrix in LDS), decomposition, the
+// register kernels' [DP][DP] copy of U and the moment centre.  Element by element the arithmetic of the kernels above
+// (which are the host's): a 64-row panel sees the same subtractions in the same order as two 32-row panels and a
+// trailing update.  Twelve launches per window become one at the headline's D = 50.
+constexpr int kSmallDim = 64;
+__global__ void __launch_bounds__(512) pooled_small_update_kernel(const PooledUpdateParams p, const PooledPublishParams q) {
+    __shared__ double R[kSmallDim][kSmallDim + 1];
+    __shared__ double s_piv;
+    __shared__ int s_state;    // kPooledOk ...
+    const int D = p.D;
+    const int tid = threadIdx.x;
+    const double* S1 = p.M + (size_t)D * (D + 1) / 2;
+    const double n = S1[D];
+    if (!(n > 0.0)) {          // no point was folded: no update (uniform: every thread reads the same word)
+        if (tid == 0) p.scal[kPsStatus] = kPooledSkipped;
+        return;
+    }
+    // ---- SharedProposal::absorbMoments ----
+    const double centre_trials0 = p.scal[kPsCentreTrials], cov_trials0 = p.scal[kPsCovTrials];
+    for (int k = tid; k < D * (D + 1) / 2; k += 512) {
+        int i = (int)((__builtin_sqrt(8.0 * (double)k + 1.0) - 1.0) * 0.5);
+        while ((i + 1) * (i + 2) / 2 <= k) ++i;
+        while (i * (i + 1) / 2 > k) --i;
+        const int j = k - i * (i + 1) / 2;
+        const double di = S1[i] / (centre_trials0 + n);
+        const double dj = S1[j] / (centre_trials0 + n);
+        double b = p.M[k];
+        b -= S1[i] * dj;
+        b -= di * S1[j];
+        b += (n * di) * dj;
+        double v = p.cov[(size_t)i * D + j];
+        v *= cov_trials0;
+        v += b;
+        v /= cov_trials0 + n;
+        p.cov[(size_t)i * D + j] = v;
+        p.cov[(size_t)j * D + i] = v;
+        R[i][j] = v;
+        R[j][i] = v;
+        if (j == 0) p.centre[i] = p.centre[i] + di;
+    }
+    __syncthreads();
+    // ---- trials and the scalar half of SharedProposal::update ----
+    if (tid == 0) {
+        double centre_trials = pu_min(p.cov_window, centre_trials0 + n);
+        double cov_trials = pu_min(p.cov_window, cov_trials0 + n);
+        double trace = 0.0;
+        for (int d = 0; d < D; ++d) trace += R[d][d];
+        int state = kPooledOk;
+        if (trace <= 0) {
+            state = kPooledInvalidTrace;
+        } else {
+            const double scale = __builtin_sqrt(p.scal[kPsSigmaTrace] / trace);
+            p.scal[kPsSigma] = p.scal[kPsSigma] * scale;
+            p.scal[kPsSigmaTrace] = trace;
+            p.scal[kPsLastScale] = scale;
+            if (p.cov_deweight > 0.0) {
+                const double w = 1.0 - pu_min(p.cov_deweight, 1.0);
+                cov_trials = pu_max(1.0, w * cov_trials);
+                cov_trials = pu_min(cov_trials, w * p.cov_window);
+                centre_trials = pu_max(1.0, w * centre_trials);
+                centre_trials = pu_min(centre_trials, w * p.cov_window);
+            }
+        }
+        p.scal[kPsCentreTrials] = centre_trials;
+        p.scal[kPsCovTrials] = cov_trials;
+        s_state = state;
+    }
+    __syncthreads();
+    // the moments of the next window are taken about the centre the running average now holds, whatever becomes of U
+    for (int d = tid; d < D; d += 512) q.c0[d] = p.centre[d];
+    if (s_state != kPooledOk) {
+        if (tid == 0) p.scal[kPsStatus] = s_state;
+        return;
+    }
+    // ---- SharedProposal::cholesky: row c of U from the rows above it, one thread per column ----
+    const int jj = tid;
+    for (int c = 0; c < D; ++c) {
+        double v = 0.0;
+        if (jj >= c && jj < D) {
+            v = R[c][jj];
+            for (int rr = 0; rr < c; ++rr) v -= R[rr][jj] * R[rr][c];
+            if (jj == c) {
+                if (!(v > 0.0) || !__builtin_isfinite(v)) {
+                    s_state = kPooledCholeskyFailed;
+                } else {
+                    const double piv = __builtin_sqrt(v);
+                    R[c][c] = piv;
+                    s_piv = piv;
+                }
+            }
+        }
+        __syncthreads();
+        if (s_state != kPooledOk) {
+            if (tid == 0) p.scal[kPsStatus] = s_state;
+            return;
+        }
+        if (jj > c && jj < D) R[c][jj] = v / s_piv;
+        __syncthreads();
+    }
+    // ---- the decomposition (zeros below the diagonal) and the step kernels' padded copy ----
+    for (int k = tid; k < D * D; k += 512) {
+        const int r = k / D, c = k % D;
+        p.decomp[k] = (c < r) ? 0.0 : R[r][c];
+    }
+    const int DP = q.DP;
+    for (int k = tid; k < DP * DP; k += 512) {
+        const int i = k / DP, j = k % DP;
+        q.U[k] = (i < D && j < D && j >= i) ? R[i][j] : 0.0;
+    }
+    if (tid == 0) p.scal[kPsStatus] = kPooledOk;
+}
+
 }  // namespace
+
+hipError_t launch_pooled_small_update(const PooledUpdateParams& p, const PooledPublishParams& q, hipStream_t s) {
+    if (p.D < 1 || p.D > kSmallDim || q.DP < p.D) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(pooled_small_update_kernel, dim3(1), dim3(512), 0, s, p, q);
+    return hipGetLastError();
+}
 
 hipError_t launch_pooled_update(const PooledUpdateParams& p, hipStream_t s) {
     const int D = p.D;

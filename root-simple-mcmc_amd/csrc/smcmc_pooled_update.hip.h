@@ -61,6 +61,8 @@ struct PooledPublishParams {
 
 hipError_t launch_pooled_update(const PooledUpdateParams& p, hipStream_t stream);
 hipError_t launch_pooled_publish(const PooledPublishParams& p, hipStream_t stream);
+// dim <= 64 with the register kernels' layout of U (q.DP > 0): update and publish in one single-workgroup kernel
+hipError_t launch_pooled_small_update(const PooledUpdateParams& p, const PooledPublishParams& q, hipStream_t stream);
 hipError_t launch_pooled_adjust_lanes(double* lane_f64, int npad, int nchains, const double* scal, double acc_w,
                                       double acc_wW, int sigma_lane, int trials_lane, hipStream_t stream);
 hipError_t pooled_update_prepare();   // once per process, before the first launch_pooled_update

@@ -5,7 +5,8 @@ The reference itself cannot be built or imported here (it needs ROOT), and it
 ships no golden vectors, so these fixtures freeze the ORACLE's outputs (parity
 unpinned, see oracle/oracle_core.h): the CPU suite checks that the oracle still
 reproduces them, the GPU suite checks the HIP path against them without the
-oracle in the loop.  Run from the repo root:  python tests/golden/make_golden.py
+oracle in the loop.  Run from the repo root:  python tests/golden/make_golden.py   (everything)
+or  python tests/golden/make_golden.py --round2   (only the fixtures added in round 2 that are not there yet).
 """
 import os
 import sys
@@ -84,8 +85,104 @@ def hmc_chains(dim, nchains, steps, leap, eps, alpha, fused):
             "potential": np.array(pot), "acceptance": np.array(acc)}
 
 
+def tdummy_error(dim):
+    """TDummyLogLikelihood::Init() (TDummyLogLikelihood.H:44-142)."""
+    return O.dummy_error_matrix(dim)[1]
+
+
+def vaat(dim, kind, nchains, steps, exact, params=None):
+    """TSimpleMCMC<L, TProposeVAATStep>: SimpleVAAT.C's call sequence (Start, UpdateProposal, Step...)."""
+    rng = np.random.default_rng(dim + 17)
+    x0 = rng.uniform(-1.0, 1.0, size=(dim, nchains))
+    v = O.Vaat(nchains, dim, kind=kind, params=params, seed=SEED, exact=exact)
+    v.set_step_rms_window(50)
+    assert v.start(x0)
+    v.update_proposal()
+    v.step(steps)
+    qlen = int(v.lane("queue_len")[0])
+    out = {"dim": dim, "kind": kind, "nchains": nchains, "steps": steps, "exact": int(exact), "seed": SEED, "x0": x0,
+           "x": v.x, "queue_len": qlen, "queue": v.per_dim("queue")[:qlen]}
+    if params is not None:
+        out["params"] = np.asarray(params)
+    for name in ("logl", "logl_proposed", "step_rms", "proposed_value", "trials", "successes", "naccept", "last_index"):
+        out[name] = v.lane(name)
+    for name in ("sigma", "acceptance", "acceptance_trials"):
+        out[name] = v.per_dim(name)
+    return out
+
+
+def stress(dim, kind, nchains, mode, exact, window, nwin):
+    """The stress likelihoods (asymmetric, horrific, constrained) in the adaptive ensemble."""
+    rng = np.random.default_rng(kind * 31 + dim)
+    if kind == O.LIKE_ASYM:
+        x0 = rng.normal(0.3, 0.2, size=(dim, nchains))
+    elif kind == O.LIKE_HORRIFIC:
+        x0 = rng.uniform(-0.9, 0.9, size=(dim, nchains))
+    else:
+        x0 = 76.0 + rng.normal(0.0, 1.0, size=(dim, nchains))
+    prm = O.like_params(kind, dim)
+    e = O.Ensemble(nchains, dim, kind=kind, params=prm if prm.size else None, seed=SEED, mode=mode, exact=exact)
+    assert e.start(x0)
+    for _ in range(nwin):
+        e.step(window)
+        if mode == O.MODE_POOLED:
+            e.sync()
+    e.step(3)
+    return {"dim": dim, "kind": kind, "nchains": nchains, "mode": mode, "exact": int(exact), "window": window,
+            "nwin": nwin, "seed": SEED, "x0": x0, "x": e.x, "logl": e.lane("logl"), "sigma": e.lane("sigma"),
+            "naccept": e.lane("naccept"), "logl_proposed": e.lane("logl_proposed"), "covariance": e.covariance,
+            "decomposition": e.decomposition}
+
+
+def hmc_ensemble(dim, kind, nchains, schedule, params=None, fix_leapfrog=None):
+    """The HMC engine's pooled semantics: `schedule` = [(steps, gradient type), ...] after Start at 0.7."""
+    e = O.HmcEnsemble(nchains, dim, kind=kind, params=params, seed=SEED, group=64, sync_every=1,
+                      potential_from_gradient=True)
+    e.start(np.full(dim, 0.7))
+    if fix_leapfrog is not None:
+        e.set_leapfrog(fix_leapfrog)
+    for steps, gtype in schedule:
+        e.set_gradient_type(gtype)
+        e.step(steps)
+    q, m = e.state()
+    out = {"dim": dim, "kind": kind, "nchains": nchains, "seed": SEED, "group": 64, "schedule": np.array(schedule),
+           "fix_leapfrog": -1 if fix_leapfrog is None else fix_leapfrog, "q": q, "momentum": m,
+           "potential": e.lane("accepted_potential"), "mean_epsilon": e.lane("mean_epsilon"),
+           "leapfrog": e.lane("leapfrog_steps"), "reversal_len": e.lane("reversal_len"),
+           "acceptance": e.lane("current_acceptance"), "average": e.average, "covariance": e.covariance,
+           "shared": np.array([e.shared[k] for k in O.HMC_SHARED])}
+    if params is not None:
+        out["params"] = np.asarray(params)
+    return out
+
+
+def save_new(name, make):
+    """Round-2 fixtures are written only when absent (np.savez archives are not byte-stable; the old ones stay put)."""
+    path = os.path.join(HERE, name)
+    if not os.path.exists(path) or "--all" in sys.argv:
+        np.savez(path, **make())
+        print("wrote", name)
+
+
+def round2():
+    save_new("vaat_iso_d7.npz", lambda: vaat(7, O.LIKE_ISO, 70, 300, True))
+    save_new("vaat_rosenbrock_d31_fused.npz", lambda: vaat(31, O.LIKE_ROSENBROCK, 64, 200, False, [100.0]))
+    save_new("vaat_quadform_d100.npz", lambda: vaat(100, O.LIKE_QUADFORM, 64, 150, True, tdummy_error(100)))
+    save_new("stress_asym_d20_pooled.npz", lambda: stress(20, O.LIKE_ASYM, 128, O.MODE_POOLED, True, 20, 3))
+    save_new("stress_constrained_d25_pooled_fused.npz", lambda: stress(25, O.LIKE_CONSTRAINED, 128, O.MODE_POOLED, False, 20, 3))
+    save_new("stress_horrific_d75_frozen.npz", lambda: stress(75, O.LIKE_HORRIFIC, 64, O.MODE_FROZEN, True, 15, 2))
+    save_new("hmc_adaptive_iso_d20.npz", lambda: hmc_ensemble(20, O.LIKE_ISO, 70, [(30, 0)]))
+    save_new("hmc_adaptive_quadform_d100.npz",
+             lambda: hmc_ensemble(100, O.LIKE_QUADFORM, 64, [(10, 0)], params=np.linalg.inv(spd(100, 3)), fix_leapfrog=6))
+    save_new("hmc_gradient_types_d12.npz", lambda: hmc_ensemble(12, O.LIKE_ROSENBROCK, 64, [(3, 5), (3, 0), (3, 2), (2, 3)], params=[100.0]))
+
+
 def main():
     O.build()
+    if "--round2" in sys.argv:
+        round2()
+        return
+    round2()
     np.savez(os.path.join(HERE, "frozen_iso_d5.npz"), **frozen_chains(5, O.LIKE_ISO, 4, 300, np.zeros(5)))
     rng = np.random.default_rng(1)
     np.savez(os.path.join(HERE, "frozen_rosenbrock_d6.npz"),

@@ -156,3 +156,133 @@ def test_hip_reproduces_hmc_golden(gpu, name):
     q, m, logl = e.state()
     assert np.array_equal(q, g["q"]) and np.array_equal(m, g["momentum"]) and np.array_equal(-logl, g["potential"])
     assert np.array_equal(e.lane("acceptance"), g["acceptance"])
+
+
+# ---------------------------------------------------------------- round 2: VAAT, stress likelihoods, adaptive HMC
+VAAT = ["vaat_iso_d7.npz", "vaat_rosenbrock_d31_fused.npz", "vaat_quadform_d100.npz"]
+STRESS = ["stress_asym_d20_pooled.npz", "stress_constrained_d25_pooled_fused.npz", "stress_horrific_d75_frozen.npz"]
+HMC2 = ["hmc_adaptive_iso_d20.npz", "hmc_adaptive_quadform_d100.npz", "hmc_gradient_types_d12.npz"]
+
+
+def _vaat_check(g, x, lane, per_dim, qlen):
+    assert np.array_equal(x, g["x"])
+    for name in ("logl", "logl_proposed", "step_rms", "proposed_value", "trials", "successes", "naccept", "last_index"):
+        assert np.array_equal(lane(name), g[name]), name
+    for name in ("sigma", "acceptance", "acceptance_trials"):
+        assert np.array_equal(per_dim(name), g[name]), name
+    assert qlen == int(g["queue_len"]) and np.array_equal(per_dim("queue")[:qlen], g["queue"])
+
+
+@pytest.mark.parametrize("name", VAAT)
+def test_oracle_reproduces_vaat_golden(oracle, name):
+    g = _load(name)
+    v = oracle.Vaat(int(g["nchains"]), int(g["dim"]), kind=int(g["kind"]), params=g.get("params"), seed=int(g["seed"]),
+                    exact=bool(g["exact"]))
+    v.set_step_rms_window(50)
+    assert v.start(g["x0"])
+    v.update_proposal()
+    v.step(int(g["steps"]))
+    _vaat_check(g, v.x, v.lane, v.per_dim, int(v.lane("queue_len")[0]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", VAAT)
+def test_hip_reproduces_vaat_golden(gpu, name):
+    g = _load(name)
+    e = gpu.VaatEngine(int(g["dim"]), int(g["nchains"]), likelihood=int(g["kind"]), likelihood_params=g.get("params"),
+                       seed=int(g["seed"]), exact=bool(g["exact"]))
+    e.SetStepRMSWindow(50)
+    assert e.Start(g["x0"])
+    e.UpdateProposal()
+    e.Step(int(g["steps"]))
+    _vaat_check(g, e.GetAccepted(), e.lane, e.per_dim, e.queue_length)
+
+
+def _stress_run(g, make, sync_name):
+    e = make()
+    assert e.Start(g["x0"]) if hasattr(e, "Start") else e.start(g["x0"])
+    step = e.Step if hasattr(e, "Step") else e.step
+    for _ in range(int(g["nwin"])):
+        step(int(g["window"]))
+        if int(g["mode"]) == 1:
+            e.sync()
+    step(3)
+    return e
+
+
+def _stress_check(g, x, lane, cov, dec):
+    assert np.array_equal(x, g["x"])
+    for name in ("logl", "sigma", "naccept", "logl_proposed"):
+        assert np.array_equal(lane(name), g[name]), name
+    assert np.array_equal(cov, g["covariance"]) and np.array_equal(dec, g["decomposition"])
+
+
+@pytest.mark.parametrize("name", STRESS)
+def test_oracle_reproduces_stress_golden(oracle, name):
+    g = _load(name)
+    dim, kind = int(g["dim"]), int(g["kind"])
+    prm = oracle.like_params(kind, dim)
+    e = _stress_run(g, lambda: oracle.Ensemble(int(g["nchains"]), dim, kind=kind, params=prm if prm.size else None,
+                                               seed=int(g["seed"]), mode=int(g["mode"]), exact=bool(g["exact"])), "sync")
+    _stress_check(g, e.x, e.lane, e.covariance, e.decomposition)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", STRESS)
+def test_hip_reproduces_stress_golden(gpu, name):
+    g = _load(name)
+    dim, kind = int(g["dim"]), int(g["kind"])
+    # the parameters of the likelihoods as the reference's headers fix them (constrained: example4's Init())
+    prm = None
+    if kind == 6:
+        expected = np.full(dim, 76.0); prior = np.full(dim, 76.0 * 0.08)
+        expected[-1], prior[-1] = 80.0, 2.0
+        prm = np.concatenate([[1902.0, 16.0], expected, prior])
+    e = _stress_run(g, lambda: gpu.Engine(dim, int(g["nchains"]), likelihood=kind, likelihood_params=prm, seed=int(g["seed"]),
+                                          mode=int(g["mode"]), exact=bool(g["exact"])), "sync")
+    _stress_check(g, e.GetAccepted(), e.lane, e.covariance, e.decomposition)
+
+
+def _hmc2_check(g, q, m, potential, lane_eps, lane_l, lane_rev, lane_acc, average, covariance, shared):
+    assert np.array_equal(q, g["q"]) and np.array_equal(m, g["momentum"]) and np.array_equal(potential, g["potential"])
+    assert np.array_equal(lane_eps, g["mean_epsilon"]) and np.array_equal(lane_l, g["leapfrog"].astype(lane_l.dtype))
+    assert np.array_equal(lane_rev, g["reversal_len"]) and np.array_equal(lane_acc, g["acceptance"])
+    assert np.array_equal(average, g["average"]) and np.array_equal(covariance, g["covariance"])
+    assert np.array_equal(shared, g["shared"])
+
+
+@pytest.mark.parametrize("name", HMC2)
+def test_oracle_reproduces_adaptive_hmc_golden(oracle, name):
+    g = _load(name)
+    dim = int(g["dim"])
+    e = oracle.HmcEnsemble(int(g["nchains"]), dim, kind=int(g["kind"]), params=g.get("params"), seed=int(g["seed"]),
+                           group=int(g["group"]), sync_every=1, potential_from_gradient=True)
+    e.start(np.full(dim, 0.7))
+    if int(g["fix_leapfrog"]) >= 0:
+        e.set_leapfrog(int(g["fix_leapfrog"]))
+    for steps, gtype in g["schedule"]:
+        e.set_gradient_type(int(gtype))
+        e.step(int(steps))
+    q, m = e.state()
+    _hmc2_check(g, q, m, e.lane("accepted_potential"), e.lane("mean_epsilon"), e.lane("leapfrog_steps"), e.lane("reversal_len"),
+                e.lane("current_acceptance"), e.average, e.covariance, np.array([e.shared[k] for k in oracle.HMC_SHARED]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", HMC2)
+def test_hip_reproduces_adaptive_hmc_golden(gpu, name):
+    g = _load(name)
+    dim = int(g["dim"])
+    e = gpu.HmcEngine(dim, int(g["nchains"]), likelihood=int(g["kind"]), likelihood_params=g.get("params"), seed=int(g["seed"]))
+    assert e.moment_group == int(g["group"])      # the fixture's moment groups are the engine's for this ensemble size
+    e.Start(np.full(dim, 0.7))
+    if int(g["fix_leapfrog"]) >= 0:
+        e.SetLeapFrog(int(g["fix_leapfrog"]))
+    for steps, gtype in g["schedule"]:
+        e.Step(int(steps), gradient_type=int(gtype))
+    q, m, logl = e.state()
+    t = e.tuning
+    shared = np.array([t[k] for k in ("trace", "orbit", "updates", "cov_trials", "average_trials", "steps_remaining",
+                                      "steps_since_update", "max_scale", "min_scale", "est_trace")])
+    _hmc2_check(g, q, m, -logl, e.lane("mean_epsilon"), e.lane("leapfrog"), e.lane("reversal_len"), e.lane("acceptance"),
+                e.average, e.covariance, shared)

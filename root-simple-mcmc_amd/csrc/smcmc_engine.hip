@@ -102,6 +102,10 @@ struct smcmc_engine {
     double* h_moments = nullptr;   // pinned host copy of the packed moments (read back at every sync)
     double* d_forced = nullptr;
     double* d_scratch = nullptr;   // dim > 63, quadratic form in reference order: the proposal image its serial sum reads
+    // dim > 63, pooled covariance fed every step: the accepted point after each step of a launch, for the folds that follow it
+    double* d_ring = nullptr;      // [ring_steps][dim][npad]
+    double* d_ring_logl = nullptr; // [ring_steps][npad] (the kernels save both)
+    int ring_steps = -1;           // -1: not decided yet; 0: no ring (the state is too large), else steps per launch
     ncclComm_t comm = nullptr;     // smcmc_comm_init
     int comm_ranks = 0;
     double* d_proposed = nullptr;  // [dp][npad], allocated by SMCMC_P_KEEP_PROPOSED
@@ -586,6 +590,20 @@ int device_apply(smcmc_engine* h) {
     return SMCMC_OK;
 }
 
+// The ring of per-step states behind multi-step launches of the pooled large-dimension path (at most 8 steps, at
+// most 2 GiB); 0 steps when even two states do not fit the budget.
+int ensure_ring(smcmc_engine* h) {
+    if (h->ring_steps >= 0) return SMCMC_OK;
+    const size_t state = sizeof(double) * (size_t)h->npad * h->dim;
+    size_t steps = ((size_t)2 << 30) / state;
+    if (steps > 8) steps = 8;
+    if (steps < 2) { h->ring_steps = 0; return SMCMC_OK; }
+    HIP_TRY(h, hipMalloc(&h->d_ring, state * steps));
+    HIP_TRY(h, hipMalloc(&h->d_ring_logl, sizeof(double) * (size_t)h->npad * steps));
+    h->ring_steps = (int)steps;
+    return SMCMC_OK;
+}
+
 StepParams make_params(smcmc_engine* h, int nsteps, int metropolis) {
     const SharedProposal& P = *h->prop;
     StepParams p;
@@ -691,8 +709,44 @@ int launch(smcmc_engine* h, int nsteps, int metropolis, int stride, double* save
         // POOLED: the point UpdateState sees at the start of step t is folded into the moments
         // when (t - 1) % moment_stride == 0; the step launches are cut at those steps
         int done = 0;
+        // Covariance fed every step: a launch of several steps leaves the point after each of them in a ring, and the
+        // folds of those points follow the launch, in step order -- the order of a fold between every two one-step
+        // launches, without their state round trips (255 us each at config 4 in the fused order).
+        const bool ring_wanted = pooled && h->moment_stride == 1 && !q.has_forced && q.scan_dim < 0 && nsteps >= 2;
+        if (ring_wanted) {
+            int rst = ensure_ring(h);
+            if (rst) return rst;
+        }
         while (done < nsteps) {
             int seg = nsteps - done;
+            if (ring_wanted && h->ring_steps >= 2 && seg >= 2) {
+                seg = std::min(seg, h->ring_steps);
+                hipError_t e = launch_fold(h->d_x, h->d_c0, h->nchains, h->npad, h->dim, h->slice_chains, h->fold_nslices, h->d_gacc,
+                                           h->stream);
+                if (e != hipSuccess) return fail(h, SMCMC_ERR_HIP, std::string("fold kernel launch: ") + hipGetErrorString(e));
+                q.nsteps = seg;
+                q.step0 = h->total_steps;
+                q.save_x = h->d_ring; q.save_logl = h->d_ring_logl; q.save_stride = 1;
+                if (!exact) {
+                    q.Uperm = h->d_Uop;
+                    e = launch_panel_mfma(q, h->likelihood, h->stream);
+                } else {
+                    q.Uperm = h->d_U;
+                    e = (h->panel_w == 4) ? launch_panel<4, kPanelCW>(q, h->likelihood, exact, h->stream)
+                                          : launch_panel<8, kPanelCW>(q, h->likelihood, exact, h->stream);
+                }
+                if (e != hipSuccess) return fail(h, SMCMC_ERR_HIP, std::string("panel kernel launch: ") + hipGetErrorString(e));
+                q.save_x = nullptr; q.save_logl = nullptr;
+                // the point after step s of the launch is the one UpdateState sees at the start of step s + 1
+                for (int s = 0; s + 1 < seg; ++s) {
+                    e = launch_fold(h->d_ring + (size_t)s * h->dim * h->npad, h->d_c0, h->nchains, h->npad, h->dim, h->slice_chains,
+                                    h->fold_nslices, h->d_gacc, h->stream);
+                    if (e != hipSuccess) return fail(h, SMCMC_ERR_HIP, std::string("fold kernel launch: ") + hipGetErrorString(e));
+                }
+                h->total_steps += (uint32_t)seg;
+                done += seg;
+                continue;
+            }
             if (pooled) {
                 const int phase = (int)(h->total_steps % (uint32_t)h->moment_stride);
                 // a forced step or a scan does not call UpdateState: nothing to fold
@@ -846,6 +900,7 @@ int smcmc_destroy(smcmc_engine* h) {
     (void)hipFree(h->d_U); (void)hipFree(h->d_Uop); (void)hipFree(h->d_like); (void)hipFree(h->d_c0); (void)hipFree(h->d_gacc);
     (void)hipFree(h->d_moments); (void)hipFree(h->d_chunks); (void)hipHostFree(h->h_moments);
     (void)hipFree(h->d_centre); (void)hipFree(h->d_cov); (void)hipFree(h->d_decomp); (void)hipFree(h->d_scal);
+    (void)hipFree(h->d_ring); (void)hipFree(h->d_ring_logl);
     (void)hipHostFree(h->h_scal);
     if (h->status_event) (void)hipEventDestroy(h->status_event);
     delete h->prop;

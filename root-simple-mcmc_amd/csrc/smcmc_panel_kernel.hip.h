@@ -534,7 +534,10 @@ __global__ void __launch_bounds__(W * kWave) panel_step_kernel(const PanelParams
 #pragma unroll
             for (int jl = 0; jl < CW; ++jl) {
                 const int j = jl * W + w;
-                if (j < D) p.save_x[(slot * (size_t)D + (size_t)j) * (W == 4 ? NPl : NP) + chain] = take ? proposal(jl, j) : p.x[(size_t)j * (W == 4 ? NPl : NP) + chain];
+                if (j < D)
+                    // (streaming store: a save that allocates in L2 evicts U and the state the next step reads)
+                    __builtin_nontemporal_store(take ? proposal(jl, j) : p.x[(size_t)j * (W == 4 ? NPl : NP) + chain],
+                                                &p.save_x[(slot * (size_t)D + (size_t)j) * (W == 4 ? NPl : NP) + chain]);
             }
             if (w == 0) p.save_logl[slot * (W == 4 ? NPl : NP) + chain] = logl;
         }

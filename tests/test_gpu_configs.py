@@ -418,3 +418,27 @@ def test_overlapped_update_changes_nothing_without_a_fallback(gpu):
         a.Step(8); b.Step(8)
         a.sync(); b.sync()
     _same_engines(a, b, "overlap vs parity mode")
+
+
+@pytest.mark.parametrize("exact", [True, False])
+@pytest.mark.parametrize("dim,n,kind", [(100, 192, 0), (200, 128, 2), (500, 64, 1)])
+def test_pooled_every_step_through_the_ring(gpu, oracle, dim, n, kind, exact):
+    """Covariance fed every step at D > 63: launches of up to eight steps leave each step's point in a ring and the
+    folds follow in step order -- the same moments, bit for bit, as a fold between one-step launches (windows of 19 and
+    3 steps cut the launches at 8 + 8 + 3 and 3; a window of 1 takes the one-step path)."""
+    if kind == 1 and exact:
+        pytest.skip("the serial quadratic form at D = 500 is covered by test_gpu_parity (slow on the oracle)")
+    e, o = _pair(gpu, oracle, dim, n, kind, gpu.MODE_POOLED, exact, rowwise=(kind == 1 and not exact), stride=1)
+    rng = np.random.default_rng(dim)
+    x0 = rng.uniform(0.5, 1.5, size=(dim, n)) if kind == 2 else np.full(dim, 0.02)
+    assert e.Start(x0) and o.start(x0)
+    for window in (19, 3, 1):
+        e.Step(window); o.step(window)
+        _same(e, o, f"window {window}")
+        e.reduce_moments()
+        assert np.array_equal(e.read_moments(), o.reduce_moments()), f"window {window}: moments"
+        o_m = e.read_moments()
+        e.apply_moments(); o.apply_moments(o_m)
+        _same_shared(e, o, f"window {window}")
+    e.Step(2); o.step(2)
+    _same(e, o, "end")

@@ -402,10 +402,10 @@ __global__ void __launch_bounds__(kPmW* kWave, 1) panel_mfma_kernel(const PanelP
                         const int i = comp(t, r);
                         const bool mine = owns(t) && i < D;
                         if (take) {
-                            if (mine && chain < p.nchains) p.x[(size_t)i * NP + chain] = xp[t][ct][r];
+                            if (mine && chain < p.nchains) __builtin_nontemporal_store(xp[t][ct][r], &p.x[(size_t)i * NP + chain]);
                             x[t][ct][r] = xp[t][ct][r];
                         } else {
-                            x[t][ct][r] = mine ? p.x[(size_t)i * NP + chain] : 0.0;
+                            x[t][ct][r] = mine ? __builtin_nontemporal_load(&p.x[(size_t)i * NP + chain]) : 0.0;
                         }
                     } else {
                         x[t][ct][r] = take ? xp[t][ct][r] : x[t][ct][r];

@@ -598,8 +598,15 @@ int ensure_ring(smcmc_engine* h) {
     size_t steps = ((size_t)2 << 30) / state;
     if (steps > 8) steps = 8;
     if (steps < 2) { h->ring_steps = 0; return SMCMC_OK; }
-    HIP_TRY(h, hipMalloc(&h->d_ring, state * steps));
-    HIP_TRY(h, hipMalloc(&h->d_ring_logl, sizeof(double) * (size_t)h->npad * steps));
+    // no memory for the ring is no error: the one-step launches with a fold between them need none
+    if (hipMalloc(&h->d_ring, state * steps) != hipSuccess ||
+        hipMalloc(&h->d_ring_logl, sizeof(double) * (size_t)h->npad * steps) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipFree(h->d_ring); (void)hipFree(h->d_ring_logl);
+        h->d_ring = nullptr; h->d_ring_logl = nullptr;
+        h->ring_steps = 0;
+        return SMCMC_OK;
+    }
     h->ring_steps = (int)steps;
     return SMCMC_OK;
 }

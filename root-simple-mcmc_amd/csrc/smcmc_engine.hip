@@ -1531,6 +1531,7 @@ int smcmc_read_lane_f64(smcmc_engine* h, int field, double* out) {
 int smcmc_read_lane_i32(smcmc_engine* h, int field, int32_t* out) {
     if (!h || !out || field < 0 || field >= SMCMC_LANE_I32_COUNT_) return SMCMC_ERR_INVALID;
     ON_DEVICE(h);
+    { int sst_ = check_pending(h); if (sst_) return sst_; }   // a fallback that ends in ResetProposal clears the counters
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     HIP_TRY(h, hipMemcpy(out, h->d_lane_i32 + (size_t)field * h->npad, (size_t)h->nchains * sizeof(int32_t),
                          hipMemcpyDeviceToHost));

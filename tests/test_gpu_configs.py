@@ -385,24 +385,28 @@ def test_device_update_is_the_host_update(gpu, dim, n, exact):
     assert a.get_param("UPDATE_COUNT") >= 5 and a.get_param("LAST_UPDATE_PATH") == 0
 
 
+@pytest.mark.parametrize("rung", [1, 2, 3])   # rung 4's matrix (variances next to DBL_MAX) overflows in any running average
 @pytest.mark.parametrize("dim,n", [(6, 70), (100, 64)])
-def test_device_update_falls_back_to_the_host_ladder(gpu, dim, n):
+def test_device_update_falls_back_to_the_host_ladder(gpu, dim, n, rung):
     """A covariance the plain Cholesky decomposition cannot take: the device raises its status word, the host runs the
-    ladder (TSimpleMCMC.H:1134-1389) from there, and the result is what the all-host update gives."""
+    ladder (TSimpleMCMC.H:1134-1389) from there -- conditioning, eigen-decomposition, emergency shrink, reset -- and the
+    result is what the all-host update gives."""
     a, b = _ab(gpu, dim, n, 0, True)
     x0 = np.zeros(dim)
     assert a.Start(x0) and b.Start(x0)
     a.Step(4); b.Step(4)
     a.sync(); b.sync()
-    cov = _broken_covariance(dim, 2)
+    cov = _broken_covariance(dim, rung)
     for e in (a, b):
         e.SetCovariance(cov)
         e.set_param("COVARIANCE_TRIALS", 1e12)          # the folded points barely move it
     a.Step(4); b.Step(4)
     a.sync(); b.sync()
-    assert a.get_param("LAST_UPDATE_PATH") == 2 and b.get_param("LAST_UPDATE_PATH") == 2
+    assert a.get_param("LAST_UPDATE_PATH") == b.get_param("LAST_UPDATE_PATH") and a.get_param("LAST_UPDATE_PATH") >= 1
     _same_engines(a, b, "after the fallback")
-    assert np.abs(np.tril(a.decomposition, -1)).max() > 0            # an eigen-decomposition: the FULLU kernels run next
+    if rung == 2:
+        assert a.get_param("LAST_UPDATE_PATH") == 2
+        assert np.abs(np.tril(a.decomposition, -1)).max() > 0        # an eigen-decomposition: the FULLU kernels run next
     a.Step(5); b.Step(5)
     a.sync(); b.sync()                                               # and the next update goes back to plain Cholesky or not,
     _same_engines(a, b, "one window later")                          # identically

@@ -596,10 +596,16 @@ void oracle_hmc_ensemble_sync(oracle_hmc_ensemble* e) {
     const size_t npk = hmce_npacked(D);
     hmc_shared* s = e->shared;
     double* M = (double*)calloc(npk, sizeof(double));
+    /* the engine's reduction order (fold_reduce_kernel, as oracle_ensemble_reduce_moments): groups in ascending order
+     * within chunks of 32, then the chunk sums in ascending order */
     for (size_t k = 0; k < npk; ++k) {
-        double t = 0.0;
-        for (int g = 0; g < e->ngroups; ++g) t += e->acc[(size_t)g * npk + k];
-        M[k] = t;
+        double total = 0.0;
+        for (int g0 = 0; g0 < e->ngroups; g0 += 32) {
+            double t = 0.0;
+            for (int g = g0; g < e->ngroups && g < g0 + 32; ++g) t += e->acc[(size_t)g * npk + k];
+            total += t;
+        }
+        M[k] = total;
     }
     memset(e->acc, 0, sizeof(double) * (size_t)e->ngroups * npk);
     const int steps = e->steps_in_window;

@@ -171,7 +171,9 @@ static __global__ void __launch_bounds__(kFoldWaves* kWave) fold_moments_kernel(
             }
 }
 
-// packed element k = (i, j), j <= i <= D  ->  sum over slices (ascending) of its tile entry
+// packed element k = (i, j), j <= i <= D  ->  sum over slices of its tile entry, in the order of every moment reduction
+// of the engine (reduce_chunks_kernel / reduce_final_kernel for dim <= 63, oracle_ensemble_reduce_moments): slices in
+// ascending order within chunks of kReduceChunk = 32, then the chunk sums in ascending order
 static __global__ void fold_reduce_kernel(const double* __restrict__ gacc, int ntiles, int nslices, int D,
                                    double* __restrict__ moments) {
     const int npk = (D + 1) * (D + 2) / 2;
@@ -184,9 +186,14 @@ static __global__ void fold_reduce_kernel(const double* __restrict__ gacc, int n
     const int ti = i >> 4, tj = j >> 4, ii = i & 15, jj = j & 15;
     const int reg = ii >> 2, lane = jj + 16 * (ii & 3);   // C/D layout: column = lane & 15, row = (lane >> 4) + 4*reg
     const int tile = ti * (ti + 1) / 2 + tj;
-    double s = 0.0;
-    for (int sl = 0; sl < nslices; ++sl) s += gacc[(((size_t)sl * ntiles + tile) * 4 + reg) * kWave + lane];
-    moments[k] = s;
+    double total = 0.0;
+    for (int sl0 = 0; sl0 < nslices; sl0 += kReduceChunk) {
+        double s = 0.0;
+        for (int sl = sl0; sl < nslices && sl < sl0 + kReduceChunk; ++sl)
+            s += gacc[(((size_t)sl * ntiles + tile) * 4 + reg) * kWave + lane];
+        total += s;
+    }
+    moments[k] = total;
 }
 
 hipError_t launch_fold(const double* x, const double* c0, int nchains, int npad, int D, int slice_chains, int nslices,

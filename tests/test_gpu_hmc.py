@@ -313,3 +313,14 @@ def test_hmc_approximate_gradient_schedule(gpu, oracle, kind, dim):
     e.Step(20, gradient_type=2); o.step(20)
     _same_hmc(e, o, "run")
     assert e.lane("naccept").sum() > 0
+
+
+def test_hmc_more_moment_groups_than_one_reduction_chunk(gpu, oracle):
+    """40 moment groups of 64 chains: the pooled UpdateCovariance adds the group sums in chunks of 32, like every moment
+    reduction of the engine."""
+    dim, n = 20, 64 * 40
+    e, o = _adaptive_pair(gpu, oracle, dim, n, 0, None, True, 1)
+    assert e.moment_group == 64
+    e.Start(np.ones(dim)); o.start(np.ones(dim))
+    e.Step(6); o.step(6)
+    _same_hmc(e, o, "six steps")

@@ -53,6 +53,12 @@ struct smcmc_hmc {
     double *d_Eperm = nullptr;     // QUADFORM: Error in hmc_step_kernel's layout (d_E holds the matrix kernels')
     double *d_covE = nullptr, *d_cov_avg = nullptr, *d_fd_grad = nullptr;
     bool cov_dirty = true;         // fEstimatedError / fAveragePoint changed since the last upload
+    // the running average point / covariance on the device (hmc_absorb_* kernels): the host copy in *shared follows
+    // on demand (hmc_pull) or when UpdateErrorMatrix decides to run
+    double *d_avg = nullptr, *d_exxt = nullptr, *d_hcov = nullptr, *d_hscal = nullptr;
+    double* h_hscal = nullptr;     // pinned: {n, average trials, covariance trials, trace}
+    bool host_stale = false;       // the device holds newer average / covariance than *shared
+    bool shared_on_device = false; // hmc_push has run since the host last (re)initialised *shared
     std::string error;
 };
 
@@ -182,7 +188,10 @@ int hmc_generic_buffers(smcmc_hmc* h) {
         if (h->cov_dirty) {
             const std::vector<double> perm = hmc_permute(h, h->shared->error.data());
             HMC_TRY(h, hipMemcpyAsync(h->d_covE, perm.data(), perm_bytes, hipMemcpyHostToDevice, h->stream));
-            HMC_TRY(h, hipMemcpyAsync(h->d_cov_avg, h->shared->average.data(), sizeof(double) * D, hipMemcpyHostToDevice, h->stream));
+            if (h->shared_on_device)   // the running average lives on the device
+                HMC_TRY(h, hipMemcpyAsync(h->d_cov_avg, h->d_avg, sizeof(double) * D, hipMemcpyDeviceToDevice, h->stream));
+            else
+                HMC_TRY(h, hipMemcpyAsync(h->d_cov_avg, h->shared->average.data(), sizeof(double) * D, hipMemcpyHostToDevice, h->stream));
             HMC_TRY(h, hipStreamSynchronize(h->stream));   // the staging vector goes out of scope
             h->cov_dirty = false;
         }
@@ -210,11 +219,97 @@ int hmc_tracking_buffers(smcmc_hmc* h) {
     HMC_TRY(h, hipMalloc(&h->d_moments, sizeof(double) * hmc_npacked(h)));
     HMC_TRY(h, hipMalloc(&h->d_zero, sizeof(double) * h->dim));
     HMC_TRY(h, hipHostMalloc((void**)&h->h_moments, sizeof(double) * hmc_npacked(h), hipHostMallocDefault));
+    HMC_TRY(h, hipMalloc(&h->d_avg, sizeof(double) * h->dim));
+    HMC_TRY(h, hipMalloc(&h->d_exxt, sizeof(double) * (size_t)h->dim * h->dim));
+    HMC_TRY(h, hipMalloc(&h->d_hcov, sizeof(double) * (size_t)h->dim * h->dim));
+    HMC_TRY(h, hipMalloc(&h->d_hscal, sizeof(double) * 8));
+    HMC_TRY(h, hipHostMalloc((void**)&h->h_hscal, sizeof(double) * 8, hipHostMallocDefault));
+    h->shared_on_device = false;
     HMC_TRY(h, hipMemsetAsync(h->d_p0, 0, vec, h->stream));
     HMC_TRY(h, hipMemsetAsync(h->d_qprev, 0, vec, h->stream));
     HMC_TRY(h, hipMemsetAsync(h->d_gacc, 0, sizeof(double) * hmc_gacc_doubles(h), h->stream));
     HMC_TRY(h, hipMemsetAsync(h->d_moments, 0, sizeof(double) * hmc_npacked(h), h->stream));
     HMC_TRY(h, hipMemsetAsync(h->d_zero, 0, sizeof(double) * h->dim, h->stream));
+    return SMCMC_OK;
+}
+
+// ---- UpdateCovariance (TSimpleHMC.H:665-695) fed with a batch, on the device: the arithmetic of HmcShared::absorb ----
+enum { kHsN = 0, kHsAverageTrials, kHsCovTrials, kHsTrace, kHsCount };
+
+__global__ void hmc_absorb_average_kernel(const double* M, int D, double* avg, const double* scal) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= D) return;
+    const double* S1 = M + (size_t)D * (D + 1) / 2;
+    const double n = S1[D];
+    if (!(n > 0.0)) return;
+    const double trials = scal[kHsAverageTrials];
+    double v = avg[i];                                                   // :671-677
+    v *= trials;
+    v += S1[i];
+    v /= trials + n;
+    avg[i] = v;
+}
+
+__global__ void __launch_bounds__(256) hmc_absorb_cov_kernel(const double* M, int D, const double* avg, double* exxt, double* cov,
+                                                             const double* scal) {
+    const int j = blockIdx.x * 16 + (threadIdx.x & 15);
+    const int i = blockIdx.y * 16 + (threadIdx.x >> 4);
+    if (i >= D || j > i) return;
+    const double n = M[(size_t)D * (D + 1) / 2 + D];
+    if (!(n > 0.0)) return;
+    const double trials = scal[kHsCovTrials];
+    double v = exxt[(size_t)i * D + j];                                  // :681-691
+    v *= trials;
+    v += M[(size_t)i * (i + 1) / 2 + j];
+    v /= trials + n;
+    exxt[(size_t)i * D + j] = v;
+    exxt[(size_t)j * D + i] = v;
+    const double c = v - avg[i] * avg[j];
+    cov[(size_t)i * D + j] = c;
+    cov[(size_t)j * D + i] = c;
+}
+
+// trial counts (:678-679, 692-693) and the trace UpdateErrorMatrix looks at (:708-711): one wavefront
+__global__ void __launch_bounds__(64) hmc_absorb_scalars_kernel(const double* M, int D, const double* cov, double* scal,
+                                                                double cov_window) {
+    __shared__ double diag[512];
+    for (int d = threadIdx.x; d < D; d += 64) diag[d] = cov[(size_t)d * D + d];
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    const double n = M[(size_t)D * (D + 1) / 2 + D];
+    scal[kHsN] = n;
+    if (!(n > 0.0)) return;
+    scal[kHsAverageTrials] = __builtin_fmin(cov_window, scal[kHsAverageTrials] + n);
+    scal[kHsCovTrials] = __builtin_fmin(cov_window, scal[kHsCovTrials] + n);
+    double trace = 0.0;
+    for (int d = 0; d < D; ++d) trace += __builtin_fabs(diag[d]);
+    scal[kHsTrace] = trace;
+}
+
+// host copy of the running average / covariance -> device (Start, or after the host changed them)
+int hmc_push(smcmc_hmc* h) {
+    const HmcShared& S = *h->shared;
+    const size_t D = (size_t)h->dim;
+    double sc[kHsCount] = {0.0, S.averageTrials, S.covTrials, 0.0};
+    HMC_TRY(h, hipMemcpyAsync(h->d_avg, S.average.data(), D * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HMC_TRY(h, hipMemcpyAsync(h->d_exxt, S.exxt.data(), D * D * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HMC_TRY(h, hipMemcpyAsync(h->d_hcov, S.cov.data(), D * D * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HMC_TRY(h, hipMemcpyAsync(h->d_hscal, sc, sizeof(sc), hipMemcpyHostToDevice, h->stream));
+    HMC_TRY(h, hipStreamSynchronize(h->stream));
+    h->host_stale = false;
+    return SMCMC_OK;
+}
+
+// device -> host copy, when somebody asks for fAveragePoint / fEstimatedCovariance
+int hmc_pull(smcmc_hmc* h) {
+    if (!h->host_stale) return SMCMC_OK;
+    HmcShared& S = *h->shared;
+    const size_t D = (size_t)h->dim;
+    HMC_TRY(h, hipStreamSynchronize(h->stream));
+    HMC_TRY(h, hipMemcpy(S.average.data(), h->d_avg, D * sizeof(double), hipMemcpyDeviceToHost));
+    HMC_TRY(h, hipMemcpy(S.exxt.data(), h->d_exxt, D * D * sizeof(double), hipMemcpyDeviceToHost));
+    HMC_TRY(h, hipMemcpy(S.cov.data(), h->d_hcov, D * D * sizeof(double), hipMemcpyDeviceToHost));
+    h->host_stale = false;
     return SMCMC_OK;
 }
 
@@ -226,16 +321,39 @@ int hmc_sync(smcmc_hmc* h) {
     hipError_t e = launch_fold_reduce(h->d_gacc, h->dim, h->fold_nslices, h->d_moments, h->stream);
     if (e != hipSuccess) return hfail(h, SMCMC_ERR_HIP, std::string("fold reduce launch: ") + hipGetErrorString(e));
     HMC_TRY(h, hipMemsetAsync(h->d_gacc, 0, sizeof(double) * hmc_gacc_doubles(h), h->stream));
-    const double* M = h->h_moments;
-    HMC_TRY(h, hipMemcpyAsync(h->h_moments, h->d_moments, hmc_npacked(h) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HMC_TRY(h, hipStreamSynchronize(h->stream));
-    if (!(M[hmc_npacked(h) - 1] > 0.0)) return SMCMC_OK;
+    // the running averages absorb the batch on the device; four scalars come back for UpdateErrorMatrix's decision
     HmcShared& S = *h->shared;
+    if (!h->shared_on_device) {
+        int pst = hmc_push(h);
+        if (pst) return pst;
+        h->shared_on_device = true;
+    }
+    const int D = h->dim, t16 = (D + 15) / 16;
+    hipLaunchKernelGGL(hmc_absorb_average_kernel, dim3((D + 255) / 256), dim3(256), 0, h->stream, (const double*)h->d_moments, D,
+                       h->d_avg, (const double*)h->d_hscal);
+    hipLaunchKernelGGL(hmc_absorb_cov_kernel, dim3(t16, t16), dim3(256), 0, h->stream, (const double*)h->d_moments, D,
+                       (const double*)h->d_avg, h->d_exxt, h->d_hcov, (const double*)h->d_hscal);
+    hipLaunchKernelGGL(hmc_absorb_scalars_kernel, dim3(1), dim3(64), 0, h->stream, (const double*)h->d_moments, D,
+                       (const double*)h->d_hcov, h->d_hscal, S.covWindow);
+    e = hipGetLastError();
+    if (e != hipSuccess) return hfail(h, SMCMC_ERR_HIP, std::string("absorb launch: ") + hipGetErrorString(e));
+    HMC_TRY(h, hipMemcpyAsync(h->h_hscal, h->d_hscal, sizeof(double) * kHsCount, hipMemcpyDeviceToHost, h->stream));
+    HMC_TRY(h, hipStreamSynchronize(h->stream));
+    if (!(h->h_hscal[kHsN] > 0.0)) return SMCMC_OK;
     S.stepCount = (int)h->step_count;
     S.leapfrogZero = (h->leapfrog == 0);
-    S.absorb(M, steps);
+    S.absorbedOnDevice(steps, h->h_hscal[kHsAverageTrials], h->h_hscal[kHsCovTrials]);
+    h->host_stale = true;
     h->cov_dirty = true;
-    if (S.updateErrorMatrix()) {
+    bool updated = false;
+    if (S.wantsUpdate(h->h_hscal[kHsTrace])) {
+        // the O(D^3) part (eigenvalues, repair, inverse) stays on the host; it needs the covariance there
+        int pst = hmc_pull(h);
+        if (pst) return pst;
+        S.finishUpdate();
+        updated = true;
+    }
+    if (updated) {
         const int threads = 256;
         hipLaunchKernelGGL(hmc_retune_kernel, dim3((h->nchains + threads - 1) / threads), dim3(threads), 0, h->stream,
                            h->d_lane_f64, h->d_lane_i32, h->npad, h->nchains, S.maxScale, S.minScale, S.orbitLength,
@@ -311,6 +429,8 @@ int smcmc_hmc_destroy(smcmc_hmc* h) {
     (void)hipFree(h->d_E); (void)hipFree(h->d_like); (void)hipFree(h->d_lane_f64); (void)hipFree(h->d_lane_i32);
     (void)hipFree(h->d_p0); (void)hipFree(h->d_qprev); (void)hipFree(h->d_gacc); (void)hipFree(h->d_moments);
     (void)hipFree(h->d_zero); (void)hipFree(h->d_Eperm); (void)hipFree(h->d_covE); (void)hipFree(h->d_cov_avg);
+    (void)hipFree(h->d_avg); (void)hipFree(h->d_exxt); (void)hipFree(h->d_hcov); (void)hipFree(h->d_hscal);
+    (void)hipHostFree(h->h_hscal);
     (void)hipFree(h->d_fd_grad);
     (void)hipHostFree(h->h_moments);
     delete h->shared;
@@ -407,11 +527,13 @@ int smcmc_hmc_get_tuning(smcmc_hmc* h, double* out) {
 }
 int smcmc_hmc_get_average_point(smcmc_hmc* h, double* out) {
     if (!h || !out) return SMCMC_ERR_INVALID;
+    { int pst = hmc_pull(h); if (pst) return pst; }
     std::copy(h->shared->average.begin(), h->shared->average.end(), out);
     return SMCMC_OK;
 }
 int smcmc_hmc_get_covariance(smcmc_hmc* h, double* out) {
     if (!h || !out) return SMCMC_ERR_INVALID;
+    { int pst = hmc_pull(h); if (pst) return pst; }
     std::copy(h->shared->cov.begin(), h->shared->cov.end(), out);
     return SMCMC_OK;
 }
@@ -498,6 +620,8 @@ int smcmc_hmc_start(smcmc_hmc* h, const double* x0, int broadcast) {
     std::vector<double> p0(D);
     for (int d = 0; d < D; ++d) p0[d] = x[(size_t)d * NP];
     h->shared->start(p0.data());
+    h->shared_on_device = false;   // pushed again at the next pooled update
+    h->host_stale = false;
     h->cov_dirty = true;
     h->steps_in_window = 0;
     if (h->d_gacc) HMC_TRY(h, hipMemsetAsync(h->d_gacc, 0, sizeof(double) * hmc_gacc_doubles(h), h->stream));

@@ -87,18 +87,41 @@ public:
         covTrials = std::min(covWindow, covTrials + n);                      // :692-693
     }
 
-    // UpdateErrorMatrix (:703-858) without the central-point bookkeeping of :733-744 (outputs only: left to the
-    // host mirror of the class).  True when the update went through.
-    bool updateErrorMatrix() {
+    // The step counters of UpdateCovariance (:667-668) alone: the running averages of this batch were formed on the
+    // device (smcmc_hmc_engine.hip: hmc_absorb_* kernels, the arithmetic of absorb()), which hands back the trial
+    // counts it left.
+    void absorbedOnDevice(int steps, double newAverageTrials, double newCovTrials) {
+        stepsSinceUpdate += steps;
+        stepsRemaining -= steps;
+        averageTrials = newAverageTrials;
+        covTrials = newCovTrials;
+    }
+
+    // UpdateErrorMatrix's decision (:704-719) from the trace of the current covariance (sum of |diagonal|, index order)
+    bool wantsUpdate(double trace) {
         if (leapfrogZero) return false;                                      // :704
         if (covTrials < 2 * D) return false;                                 // :705
-        curTrace = 0.0;                                                      // :708-711
-        for (int i = 0; i < D; ++i) curTrace += std::fabs(cov[(size_t)i * D + i]);
+        curTrace = trace;                                                    // :708-711
         const double change = std::fabs(curTrace - estTrace);
         bool doIt = false;                                                   // :715-719
         if (stepsRemaining < 0) doIt = true;
         if (stepsSinceUpdate > 2.0 * D && change > 0.01 * estTrace) doIt = true;
-        if (!doIt) return false;
+        return doIt;
+    }
+
+    // UpdateErrorMatrix (:703-858) without the central-point bookkeeping of :733-744 (outputs only: left to the
+    // host mirror of the class).  True when the update went through.
+    bool updateErrorMatrix() {
+        double trace = 0.0;
+        if (!leapfrogZero && !(covTrials < 2 * D))
+            for (int i = 0; i < D; ++i) trace += std::fabs(cov[(size_t)i * D + i]);
+        if (!wantsUpdate(trace)) return false;
+        finishUpdate();
+        return true;
+    }
+
+    // :760-858 on the covariance in `cov`
+    void finishUpdate() {
         stepsRemaining = 2 * D + stepCount;                                  // :760
         stepsSinceUpdate = 0;
         std::vector<double> eig((size_t)D);
@@ -136,7 +159,6 @@ public:
         minScale = minS;
         invert(cov, error);                                                  // :849-850
         ++updateCount;
-        return true;
     }
 
 private:

@@ -58,3 +58,36 @@ for dim, chains, steps in ((20, 8192, 6), (500, 8192, 2)):
           f"({-(-chains // h.moment_group)} groups), {time.perf_counter() - t0:.0f} s: bit-identical {same}", flush=True)
     assert same
     h.close()
+
+# config 4 with the likelihood it names (header-form TDummy), fused row-wise order, pooled, full size
+dim, chains = 500, 32768
+prm = O.dummy_error_matrix(dim)[1]
+e = pkg.Engine(dim, chains, likelihood=1, likelihood_params=prm, mode=pkg.MODE_POOLED, exact=False)
+o = O.Ensemble(chains, dim, kind=1, params=prm, mode=O.MODE_POOLED, exact=False)
+o.set_quadform_rowwise(1)
+o.set_moment_grouping(int(e.get_param("MOMENT_GROUP")), 1)
+assert e.Start(np.full(dim, 0.02)) and o.start(np.full(dim, 0.02))
+t0 = time.perf_counter()
+e.Step(3); o.step(3); e.sync(); o.sync(); e.Step(1); o.step(1)
+same = (np.array_equal(e.GetAccepted(), o.x) and np.array_equal(e.lane("logl"), o.lane("logl"))
+        and np.array_equal(e.covariance, o.covariance) and np.array_equal(e.decomposition, o.decomposition))
+print(f"config 4 header-form TDummy, fused, pooled, {chains} chains: 3 steps + sync + 1 step, {time.perf_counter() - t0:.0f} s: "
+      f"bit-identical {same}", flush=True)
+assert same
+e.close()
+
+# a stress likelihood at the reference's dimension with the headline's chain count (large-dimension kernel, pooled)
+dim, chains = 100, 65536
+rng = np.random.default_rng(5)
+x0 = rng.normal(0.3, 0.2, size=(dim, chains))
+e = pkg.Engine(dim, chains, likelihood=4, mode=pkg.MODE_POOLED)
+o = O.Ensemble(chains, dim, kind=4, params=np.array([-1.0, 100.0]), mode=O.MODE_POOLED)
+o.set_moment_grouping(int(e.get_param("MOMENT_GROUP")), 1)
+assert e.Start(x0) and o.start(x0)
+e.Step(9); o.step(9); e.sync(); o.sync(); e.Step(2); o.step(2)
+same = (np.array_equal(e.GetAccepted(), o.x) and np.array_equal(e.lane("logl"), o.lane("logl"))
+        and np.array_equal(e.covariance, o.covariance))
+print(f"TASymLogLikelihood D={dim}, {chains} chains, pooled: 9 steps + sync + 2 steps, moment group "
+      f"{int(e.get_param('MOMENT_GROUP'))}: bit-identical {same}", flush=True)
+assert same
+e.close()

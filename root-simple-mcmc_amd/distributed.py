@@ -41,6 +41,11 @@ class HipBackend:
         self.engine.export_moments(self.buffer.data_ptr())
         return self.buffer
 
+    def local_update(self):
+        """One rank: nothing to exchange, the moments go from the reduction straight into the update."""
+        self.engine.reduce_moments()
+        self.engine.apply_moments()
+
     def moments_in(self, tensor):
         if tensor.data_ptr() != self.buffer.data_ptr():
             self.buffer.copy_(tensor)
@@ -65,6 +70,9 @@ def run_windows(backend, nwindows, window, group=None):
     for _ in range(nwindows):
         backend.step(window)
         if getattr(backend, "frozen", False):
+            continue
+        if not distributed and hasattr(backend, "local_update"):
+            backend.local_update()
             continue
         m = backend.moments_out()
         if distributed:

@@ -26,3 +26,21 @@ __device__ __forceinline__ double smcmc_user_loglike(const double (&p)[DP], smcm
     }
     return logLikelihood;
 }
+
+// The same function for 63 < dim <= 512, where a point no longer fits one lane's registers: p[i] reads coordinate i of
+// the chain's point from device memory.  Defining SMCMC_USER_LIKELIHOOD_ANY_DIM tells the build that this form exists.
+#define SMCMC_USER_LIKELIHOOD_ANY_DIM 1
+
+template <class Point>
+__device__ __forceinline__ double smcmc_user_loglike_at(const Point& p, const double* params, int D) {
+    const double positiveSlope = params[0];
+    const double negativeSlope = params[1];
+    double logLikelihood = 0.0;
+    for (int i = 0; i < D; ++i) {
+        double a = p[i];
+        if (a < 0.0) a *= negativeSlope;
+        else a *= positiveSlope;
+        logLikelihood += a;
+    }
+    return logLikelihood;
+}

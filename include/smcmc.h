@@ -46,14 +46,17 @@ typedef enum {
     /* A likelihood compiled in from user source (the `double operator()(const Vector&)` of the
      * reference's UserLikelihood concept, TSimpleMCMC.H:53-57, as a device function): a library built
      * with `python root-simple-mcmc_amd/build.py --user-likelihood my_likelihood.hip.h` carries it
-     * (INTEGRATION.md); other builds answer SMCMC_ERR_UNSUPPORTED.  dim <= 63; params = whatever the
-     * function reads (at most dim_padded^2 doubles). */
+     * (INTEGRATION.md); other builds answer SMCMC_ERR_UNSUPPORTED.  params = whatever the function reads (at most
+     * dim_padded^2 doubles).  dim <= 63 with the register form (smcmc_user_loglike<DP>); a header that also defines
+     * smcmc_user_loglike_at and SMCMC_USER_LIKELIHOOD_ANY_DIM is served up to dim = 512, above 63 in reference-order
+     * arithmetic (SMCMC_P_EXACT_ARITHMETIC = 1).  Metropolis (smcmc_*) and variable-at-a-time (smcmc_vaat_*) engines. */
     SMCMC_LIKE_USER = 3,
     /* The reference's stress targets (Metropolis engine only; they have no gradient, TSimpleHMC.H:85-89):
      * TAsymLogLikelihood.H:20-31, params = {positiveSlope, negativeSlope} (default -1, 100);
      * THorrificLogLikelihood.H:26-38 (no parameters);
      * example4/TConstrainedLikelihood.H:26-46, params = {SummedValues, SummedConstraint, ExpectedValues[dim],
-     * PriorConstraints[dim]}, dim <= 63. */
+     * PriorConstraints[dim]}.
+     * For dim > 63 all three run in reference-order arithmetic only. */
     SMCMC_LIKE_ASYM = 4,
     SMCMC_LIKE_HORRIFIC = 5,
     SMCMC_LIKE_CONSTRAINED = 6
@@ -304,8 +307,8 @@ int smcmc_hmc_read_lane_i32(smcmc_hmc* h, int field, int32_t* out);
  * N independent chains of sMCMC::TSimpleMCMC<L, sMCMC::TProposeVAATStep> (TProposeVAATStep.H:22-307, the proposal
  * SimpleVAAT.C drives): one coordinate per step from a shuffled queue of the dimensions (:52-78, 177-195), a proposal
  * width per dimension adapted to a 44 % acceptance (:219-255).  Nothing is shared between chains; chain c is the
- * reference chain on the random stream (seed, chain_offset + c).  Every likelihood id of smcmc_likelihood except USER;
- * CONSTRAINED needs dim <= 63; dim <= 512.  The reference's quirks are kept: Start resets the acceptance window to 100
+ * reference chain on the random stream (seed, chain_offset + c).  Every likelihood id of smcmc_likelihood (USER in a
+ * library built with one); dim <= 512.  The reference's quirks are kept: Start resets the acceptance window to 100
  * the first time (:211), SetGaussian's sigma is the width of Gaus() unsquared (:69-78), RestoreState / AttachState /
  * SaveState do nothing (:33-36). */
 typedef struct smcmc_vaat smcmc_vaat;

@@ -44,12 +44,13 @@ def _headers():
 
 
 def _units(user_flag=None):
-    """(source, defines, object name).  With a user likelihood only the engine and the SMCMC_LIKE_USER
+    """(source, defines, object name).  With a user likelihood only the two engines and the SMCMC_LIKE_USER
     instances are compiled with it; every other object is shared with the plain build."""
     engine = ("smcmc_engine.hip", [user_flag], "engine_user") if user_flag else ("smcmc_engine.hip", [], "engine")
+    vaat = ("smcmc_vaat_engine.hip", [user_flag], "vaat_engine_user") if user_flag else ("smcmc_vaat_engine.hip", [], "vaat_engine")
     units = [engine, ("smcmc_selftest.hip", [], "selftest"), ("smcmc_autocorr.hip", [], "autocorr"),
              ("smcmc_hmc_engine.hip", [], "hmc_engine"), ("smcmc_hmc_mfma_inst.hip", [], "hmc_mfma"),
-             ("smcmc_vaat_engine.hip", [], "vaat_engine"), ("smcmc_vaat_large.hip", [], "vaat_large"),
+             vaat, ("smcmc_vaat_large.hip", [], "vaat_large"),
              ("smcmc_pooled_update.hip", [], "pooled_update"),
              ("smcmc_panel_mfma_inst.hip", [], "panel_mfma")]
     for dp in dp_list():
@@ -64,6 +65,8 @@ def _units(user_flag=None):
     if user_flag:
         for dp in dp_list():   # SMCMC_LIKE_USER = 3
             units.append(("smcmc_inst.hip", [f"-DSMCMC_DP={dp}", "-DSMCMC_LIKE=3", user_flag], f"inst_dp{dp}_l3"))
+        for w in (4, 8):       # 63 < dim <= 512 (served when the header defines SMCMC_USER_LIKELIHOOD_ANY_DIM)
+            units.append(("smcmc_user_large.hip", [f"-DSMCMC_PANEL_W={w}", user_flag], f"user_large_w{w}"))
     return units
 
 

@@ -287,6 +287,11 @@ int upload_shared(smcmc_engine* h) {
 }
 
 int upload_like(smcmc_engine* h) {
+    if (h->panel_w && !h->d_scratch && (h->likelihood == SMCMC_LIKE_USER || h->likelihood == SMCMC_LIKE_CONSTRAINED)) {
+        // large dimensions: one lane per chain evaluates these from the proposal's [dim][chain] image
+        HIP_TRY(h, hipMalloc(&h->d_scratch, sizeof(double) * (size_t)h->npad * h->dim));
+        HIP_TRY(h, hipMemsetAsync(h->d_scratch, 0, sizeof(double) * (size_t)h->npad * h->dim, h->stream));
+    }
     if (h->likelihood == SMCMC_LIKE_QUADFORM) {
         if ((int)h->like_params.size() != h->dim * h->dim)
             return fail(h, SMCMC_ERR_INVALID, "QUADFORM needs dim*dim likelihood parameters (the Error matrix)");
@@ -661,6 +666,16 @@ StepParams make_params(smcmc_engine* h, int nsteps, int metropolis) {
     return p;
 }
 
+// the reference-order kernel for dim > 63
+hipError_t launch_panel_exact(smcmc_engine* h, const PanelParams& q) {
+#ifdef SMCMC_USER_LIKELIHOOD
+    if (h->likelihood == SMCMC_LIKE_USER)
+        return (h->panel_w == 4) ? launch_panel_user<4, kPanelCW>(q, h->stream) : launch_panel_user<8, kPanelCW>(q, h->stream);
+#endif
+    return (h->panel_w == 4) ? launch_panel<4, kPanelCW>(q, h->likelihood, true, h->stream)
+                             : launch_panel<8, kPanelCW>(q, h->likelihood, true, h->stream);
+}
+
 int launch(smcmc_engine* h, int nsteps, int metropolis, int stride, double* save_x, double* save_logl) {
     if (!h) return SMCMC_ERR_INVALID;
     ON_DEVICE(h);
@@ -702,10 +717,10 @@ int launch(smcmc_engine* h, int nsteps, int metropolis, int stride, double* save
         if (special_proposal && !exact)
             return fail(h, SMCMC_ERR_UNSUPPORTED,
                         "uniform proposals and the scan of a dimension run in reference-order arithmetic only");
-        if (stress_likelihood(h->likelihood) && !exact)
+        if ((stress_likelihood(h->likelihood) || h->likelihood == SMCMC_LIKE_USER) && !exact)
             return fail(h, SMCMC_ERR_UNSUPPORTED,
-                        "the stress likelihoods (ASYM, HORRIFIC) for dim > 63 run in reference-order arithmetic only "
-                        "(SMCMC_P_EXACT_ARITHMETIC = 1)");
+                        "the stress likelihoods (ASYM, HORRIFIC, CONSTRAINED) and user likelihoods for dim > 63 run in "
+                        "reference-order arithmetic only (SMCMC_P_EXACT_ARITHMETIC = 1)");
         if (h->likelihood == SMCMC_LIKE_QUADFORM && exact != h->exact)
             return fail(h, SMCMC_ERR_UNSUPPORTED,
                         "the quadratic-form likelihood for dim > 63 with a full (eigen) decomposition needs "
@@ -739,8 +754,7 @@ int launch(smcmc_engine* h, int nsteps, int metropolis, int stride, double* save
                     e = launch_panel_mfma(q, h->likelihood, h->stream);
                 } else {
                     q.Uperm = h->d_U;
-                    e = (h->panel_w == 4) ? launch_panel<4, kPanelCW>(q, h->likelihood, exact, h->stream)
-                                          : launch_panel<8, kPanelCW>(q, h->likelihood, exact, h->stream);
+                    e = launch_panel_exact(h, q);
                 }
                 if (e != hipSuccess) return fail(h, SMCMC_ERR_HIP, std::string("panel kernel launch: ") + hipGetErrorString(e));
                 q.save_x = nullptr; q.save_logl = nullptr;
@@ -773,8 +787,7 @@ int launch(smcmc_engine* h, int nsteps, int metropolis, int stride, double* save
                 e = launch_panel_mfma(q, h->likelihood, h->stream);
             } else {
                 q.Uperm = h->d_U;
-                e = (h->panel_w == 4) ? launch_panel<4, kPanelCW>(q, h->likelihood, exact, h->stream)
-                                      : launch_panel<8, kPanelCW>(q, h->likelihood, exact, h->stream);
+                e = launch_panel_exact(h, q);
             }
             if (e != hipSuccess) return fail(h, SMCMC_ERR_HIP, std::string("panel kernel launch: ") + hipGetErrorString(e));
             h->total_steps += (uint32_t)seg;
@@ -839,12 +852,13 @@ int smcmc_create(int dim, int nchains, int likelihood, uint64_t seed, uint32_t c
     int dp = pick_dp(dim, likelihood);
     int panel_w = 0;
     if (dp < 0) {
-        if (likelihood == SMCMC_LIKE_CONSTRAINED) return SMCMC_ERR_UNSUPPORTED;   // per-dimension parameters: dim <= 63
         // large dimensions: a workgroup of 4 or 8 wavefronts per 64-chain group (smcmc_panel_kernel.hip.h)
         if (dim <= 4 * kPanelCW) panel_w = 4;
         else if (dim <= 8 * kPanelCW) panel_w = 8;
         else return SMCMC_ERR_UNSUPPORTED;
-        if (likelihood == SMCMC_LIKE_USER) return SMCMC_ERR_UNSUPPORTED;   // user likelihoods: dim <= 63
+#ifndef SMCMC_USER_LIKELIHOOD_ANY_DIM
+        if (likelihood == SMCMC_LIKE_USER) return SMCMC_ERR_UNSUPPORTED;   // the user's header serves dim <= 63 only
+#endif
         dp = dim;
     }
     smcmc_engine* h = new (std::nothrow) smcmc_engine();
@@ -871,7 +885,7 @@ int smcmc_create(int dim, int nchains, int likelihood, uint64_t seed, uint32_t c
         HIP_TRY(h, hipMalloc(&h->d_Uop, sizeof(double) * panel_mfma_uop_doubles(dim)));
         HIP_TRY(h, hipMemset(h->d_Uop, 0, sizeof(double) * panel_mfma_uop_doubles(dim)));
     }
-    const size_t like_doubles = std::max((size_t)dp * dp, panel_w ? panel_mfma_uop_doubles(dim) : (size_t)0);
+    const size_t like_doubles = std::max((size_t)dp * dp, panel_w ? panel_mfma_uop_doubles(dim) : (size_t)0);   // >= 2 + 2 dim
     HIP_TRY(h, hipMalloc(&h->d_like, sizeof(double) * like_doubles));
     HIP_TRY(h, hipMalloc(&h->d_c0, sizeof(double) * dp));
     HIP_TRY(h, hipMalloc(&h->d_gacc, sizeof(double) * gacc_doubles(h)));
@@ -1141,8 +1155,14 @@ static int place_chains(smcmc_engine* h, const double* x0, int broadcast, std::v
         hipError_t e = launch_panel_mfma(q, h->likelihood, h->stream);
         if (e != hipSuccess) return fail(h, SMCMC_ERR_HIP, std::string("start kernel launch: ") + hipGetErrorString(e));
     } else if (h->panel_w) {
-        hipError_t e = launch_start_loglike(h->d_x, N, NP, D, h->d_like, h->d_lane_f64 + (size_t)SMCMC_LANE_LOGL * NP,
-                                            h->likelihood, h->exact, h->stream);
+        hipError_t e;
+#ifdef SMCMC_USER_LIKELIHOOD
+        if (h->likelihood == SMCMC_LIKE_USER)
+            e = launch_start_loglike_user(h->d_x, N, NP, D, h->d_like, h->d_lane_f64 + (size_t)SMCMC_LANE_LOGL * NP, h->stream);
+        else
+#endif
+        e = launch_start_loglike(h->d_x, N, NP, D, h->d_like, h->d_lane_f64 + (size_t)SMCMC_LANE_LOGL * NP,
+                                 h->likelihood, h->exact, h->stream);
         if (e != hipSuccess) return fail(h, SMCMC_ERR_HIP, std::string("start kernel launch: ") + hipGetErrorString(e));
     } else {
         StepParams p;

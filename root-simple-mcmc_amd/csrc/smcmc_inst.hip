@@ -32,7 +32,7 @@ hipError_t launch_step_like<SMCMC_DP, SMCMC_LIKE>(const StepParams& p, bool exac
     return mom ? go<DP, LIKE, false, false, true, false>(p, s) : go<DP, LIKE, false, false, false, false>(p, s);
 }
 
-#if SMCMC_LIKE != 3   // SMCMC_LIKE_USER (an enumerator, invisible to the preprocessor)
+#if SMCMC_LIKE != 3 || defined(SMCMC_USER_LIKELIHOOD)   // 3 = SMCMC_LIKE_USER (an enumerator, invisible to the preprocessor)
 // the variable-at-a-time chains on the same likelihood code (smcmc_vaat_kernel.hip.h)
 template <>
 hipError_t launch_vaat_like<SMCMC_DP, SMCMC_LIKE>(const VaatParams& p, bool exact, hipStream_t s) {

@@ -192,6 +192,11 @@ __device__ __forceinline__ double dmax(double a, double b) { return __builtin_fm
 // SMCMC_USER_LIKELIHOOD defines
 //     template <int DP> __device__ double smcmc_user_loglike(const double (&p)[DP], smcmc::cptr_f64 params, int D);
 // p[0..D) is the point (entries past D are zero), params what smcmc_set_likelihood_params handed over.
+// For 63 < dim <= 512 the point does not fit one lane's registers; a header that also defines
+//     #define SMCMC_USER_LIKELIHOOD_ANY_DIM 1
+//     template <class Point> __device__ double smcmc_user_loglike_at(const Point& p, const double* params, int D);
+// (p[i], 0 <= i < D, reads coordinate i of the chain's point from its [dim][chain] image in device memory) is served at
+// those dimensions too, in reference-order arithmetic.
 #ifdef SMCMC_USER_LIKELIHOOD
 }  // namespace smcmc
 #include SMCMC_USER_LIKELIHOOD

@@ -36,6 +36,10 @@ hipError_t launch_panel<SMCMC_PANEL_W, kPanelCW>(const PanelParams& p, int like,
             if (p.scratch == nullptr) return hipErrorInvalidValue;
             return p.special ? go_panel<W, CW, SMCMC_LIKE_QUADFORM, true>(p, s)
                              : go_panel<W, CW, SMCMC_LIKE_QUADFORM, false>(p, s);
+        case SMCMC_LIKE_CONSTRAINED:
+            if (p.scratch == nullptr) return hipErrorInvalidValue;
+            return p.special ? go_panel<W, CW, SMCMC_LIKE_CONSTRAINED, true>(p, s)
+                             : go_panel<W, CW, SMCMC_LIKE_CONSTRAINED, false>(p, s);
         default: return hipErrorInvalidValue;
     }
 }
@@ -70,6 +74,8 @@ hipError_t launch_start_loglike(const double* x, int nchains, size_t npad, int D
         hipLaunchKernelGGL(HIP_KERNEL_NAME(start_loglike_kernel<SMCMC_LIKE_ASYM, true>), grid, block, 0, s, x, nchains, npad, D, like_params, logl_out);
     } else if (like == SMCMC_LIKE_HORRIFIC) {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(start_loglike_kernel<SMCMC_LIKE_HORRIFIC, true>), grid, block, 0, s, x, nchains, npad, D, like_params, logl_out);
+    } else if (like == SMCMC_LIKE_CONSTRAINED) {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(start_loglike_kernel<SMCMC_LIKE_CONSTRAINED, true>), grid, block, 0, s, x, nchains, npad, D, like_params, logl_out);
     } else if (like == SMCMC_LIKE_QUADFORM && exact) {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(start_loglike_kernel<SMCMC_LIKE_QUADFORM, true>), dim3((nchains + 63) / 64), dim3(64), 0, s, x, nchains, npad, D, like_params, logl_out);
     } else {

@@ -117,6 +117,21 @@ __device__ __forceinline__ double quadform_serial(PointPtr pc, size_t NP, cptr_f
     return logl;
 }
 
+// one chain's point in a [dim][npad] image: what a user likelihood for dim > 63 indexes (smcmc_user_loglike_at)
+struct ChainColumn {
+    const double* base;   // &image[chain]
+    size_t pitch;         // npad
+    __device__ __forceinline__ double operator[](int i) const { return base[(size_t)i * pitch]; }
+};
+
+// likelihoods the large-dimension step kernel evaluates from the proposal's image in device memory (one lane per chain)
+template <int LIKE>
+constexpr bool kLikeFromImage = (LIKE == SMCMC_LIKE_QUADFORM || LIKE == SMCMC_LIKE_USER || LIKE == SMCMC_LIKE_CONSTRAINED);
+
+template <int LIKE, bool EXACT>
+__device__ __forceinline__ double serial_loglike(const double* __restrict__ x, int chain, size_t npad, int D,
+                                                 const double* __restrict__ like);
+
 // SPECIAL = the instantiation that also knows uniform per-dimension proposals and the scan of one dimension
 // (kept out of the common kernel: with them in, D=500 went from 0.89 to 2.85 ms/step)
 template <int W, int CW, int LIKE, bool EXACT, bool SPECIAL>
@@ -334,7 +349,7 @@ __global__ void __launch_bounds__(W * kWave) panel_step_kernel(const PanelParams
             }
         }
 
-        if constexpr (LIKE == SMCMC_LIKE_QUADFORM) {
+        if constexpr (kLikeFromImage<LIKE>) {
             // the whole proposal where one lane per chain can read it
 #pragma unroll
             for (int jl = 0; jl < CW; ++jl) {
@@ -379,7 +394,7 @@ __global__ void __launch_bounds__(W * kWave) panel_step_kernel(const PanelParams
                                 const double t = -0.5 * pj;
                                 if constexpr (EXACT) lsum += t * pj;
                                 else lsum = SMCMC_FMA(t, pj, lsum);
-                            } else if constexpr (LIKE == SMCMC_LIKE_QUADFORM) {
+                            } else if constexpr (kLikeFromImage<LIKE>) {
                                 (void)pj;   // summed below, from the global image
                             } else if constexpr (LIKE == SMCMC_LIKE_ASYM) {
                                 const double a = (pj < 0.0) ? pj * likep[1] : pj * likep[0];   // TAsymLogLikelihood.H:24-28
@@ -472,6 +487,12 @@ __global__ void __launch_bounds__(W * kWave) panel_step_kernel(const PanelParams
             }
         }
 
+        if constexpr (LIKE == SMCMC_LIKE_USER || LIKE == SMCMC_LIKE_CONSTRAINED) {
+            // one lane per chain walks the proposal's image (complete and visible since the gather's barriers) as the
+            // reference's functor walks its vector
+            if (w == 0) lsum = serial_loglike<LIKE, EXACT>(p.scratch, chain, NP, D, p.like);
+        }
+
         if constexpr (LIKE == SMCMC_LIKE_HORRIFIC) {
             const double sigma = 0.01;                                                         // :27, 34-37
             lsum /= __builtin_sqrt(D * 4.0 / 12.0);
@@ -519,7 +540,7 @@ __global__ void __launch_bounds__(W * kWave) panel_step_kernel(const PanelParams
         // QUADFORM: the proposal went to its global image before the likelihood and is taken from there, so that the
         // registers that held it are free during the serial sum
         auto proposal = [&](int jl, int j) {
-            if constexpr (LIKE == SMCMC_LIKE_QUADFORM) return p.scratch[(size_t)j * NP + chain];
+            if constexpr (kLikeFromImage<LIKE>) return p.scratch[(size_t)j * NP + chain];
             else return xp[jl];
         };
         if (take) {
@@ -569,6 +590,25 @@ template <int LIKE, bool EXACT>
 __device__ __forceinline__ double serial_loglike(const double* __restrict__ x, int chain, size_t npad, int D,
                                                  const double* __restrict__ like) {
     double lsum = 0.0;
+    if constexpr (LIKE == SMCMC_LIKE_USER) {
+#ifdef SMCMC_USER_LIKELIHOOD_ANY_DIM
+        lsum = smcmc_user_loglike_at(ChainColumn{x + chain, npad}, like, D);
+#endif
+        return lsum;
+    }
+    if constexpr (LIKE == SMCMC_LIKE_CONSTRAINED) {
+        // example4/TConstrainedLikelihood.H:26-46; like = {SummedValues, SummedConstraint, Expected[D], Prior[D]}
+        double sum = 0.0;
+        for (int i = 0; i < D; ++i) sum += x[(size_t)i * npad + chain];
+        sum = (sum - like[0]) / like[1];
+        lsum -= 0.5 * sum * sum;
+        for (int i = 0; i < D; ++i) {
+            double v = x[(size_t)i * npad + chain] - like[2 + i];
+            v /= like[2 + D + i];
+            lsum -= 0.5 * v * v;
+        }
+        return lsum;
+    }
     if constexpr (LIKE == SMCMC_LIKE_ISO_GAUSS) {
         for (int i = 0; i < D; ++i) {
             const double pi = x[(size_t)i * npad + chain];
@@ -630,5 +670,10 @@ template <int W, int CW>
 hipError_t launch_panel(const PanelParams& p, int like, bool exact, hipStream_t stream);
 hipError_t launch_start_loglike(const double* x, int nchains, size_t npad, int D, const double* like_params,
                                 double* logl_out, int like, bool exact, hipStream_t stream);
+// a user likelihood at these dimensions (smcmc_user_large.hip, user builds only)
+template <int W, int CW>
+hipError_t launch_panel_user(const PanelParams& p, hipStream_t stream);
+hipError_t launch_start_loglike_user(const double* x, int nchains, size_t npad, int D, const double* like_params,
+                                     double* logl_out, hipStream_t stream);
 
 }  // namespace smcmc

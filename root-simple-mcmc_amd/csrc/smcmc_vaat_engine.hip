@@ -81,6 +81,9 @@ int vaat_pick_dp(int dim, int like) {
 }
 
 hipError_t vaat_dispatch(smcmc_vaat* h, const VaatParams& p) {
+#ifdef SMCMC_USER_LIKELIHOOD
+    if (h->large && h->likelihood == SMCMC_LIKE_USER) return launch_vaat_large_user(p, h->exact, h->stream);
+#endif
     if (h->large) return launch_vaat_large(p, h->likelihood, h->exact, h->stream);
     switch (h->dp) {
 #define SMCMC_DP_CASE(n) case n: return launch_vaat<n>(p, h->likelihood, h->exact, h->stream);
@@ -143,6 +146,12 @@ int vaat_upload_like(smcmc_vaat* h) {
                              "CONSTRAINED needs {SummedValues, SummedConstraint, ExpectedValues[dim], PriorConstraints[dim]}");
             prm = h->like_params;
             break;
+        case SMCMC_LIKE_USER:
+            if (h->like_params.size() > std::max((size_t)DP * DP, (size_t)(2 + 2 * D)))
+                return vfail(h, SMCMC_ERR_INVALID, "a user likelihood takes at most max(dim_padded^2, 2 + 2 dim) parameters");
+            prm = h->like_params;
+            if (prm.empty()) prm = {0.0};
+            break;
         default: prm = {0.0}; break;
     }
     VAAT_TRY(h, hipMemcpyAsync(h->d_like, prm.data(), prm.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -176,7 +185,9 @@ int smcmc_vaat_create(int dim, int nchains, int likelihood, uint64_t seed, uint3
     *out = nullptr;
     if (dim < 1 || nchains < 1) return SMCMC_ERR_INVALID;
     if (likelihood < SMCMC_LIKE_ISO_GAUSS || likelihood > SMCMC_LIKE_CONSTRAINED) return SMCMC_ERR_INVALID;
-    if (likelihood == SMCMC_LIKE_USER) return SMCMC_ERR_UNSUPPORTED;
+#ifndef SMCMC_USER_LIKELIHOOD
+    if (likelihood == SMCMC_LIKE_USER) return SMCMC_ERR_UNSUPPORTED;   // this build carries no user likelihood
+#endif
     if (likelihood == SMCMC_LIKE_ROSENBROCK && dim < 2) return SMCMC_ERR_INVALID;
     if (dim > smcmc_max_dim()) return SMCMC_ERR_UNSUPPORTED;
     int ndev = 0;
@@ -184,7 +195,9 @@ int smcmc_vaat_create(int dim, int nchains, int likelihood, uint64_t seed, uint3
     if (device < 0 || device >= ndev) return SMCMC_ERR_NO_DEVICE;
     int dp = vaat_pick_dp(dim, likelihood);
     const bool large = dp < 0;
-    if (large && likelihood == SMCMC_LIKE_CONSTRAINED) return SMCMC_ERR_UNSUPPORTED;   // per-dimension parameters: dim <= 63
+#ifndef SMCMC_USER_LIKELIHOOD_ANY_DIM
+    if (large && likelihood == SMCMC_LIKE_USER) return SMCMC_ERR_UNSUPPORTED;   // the header serves dim <= 63 only
+#endif
     if (large) dp = dim;
     smcmc_vaat* h = new (std::nothrow) smcmc_vaat();
     if (!h) return SMCMC_ERR_RUNTIME;

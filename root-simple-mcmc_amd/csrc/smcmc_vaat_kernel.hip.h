@@ -286,11 +286,15 @@ inline hipError_t launch_vaat(const VaatParams& p, int like, bool exact, hipStre
         case SMCMC_LIKE_CONSTRAINED:
             if constexpr (DP == 31 || DP == 63) return launch_vaat_like<DP, SMCMC_LIKE_CONSTRAINED>(p, exact, stream);
             else return hipErrorInvalidValue;
+#ifdef SMCMC_USER_LIKELIHOOD
+        case SMCMC_LIKE_USER: return launch_vaat_like<DP, SMCMC_LIKE_USER>(p, exact, stream);
+#endif
         default: return hipErrorInvalidValue;
     }
 }
 
 // dim > 63 (smcmc_vaat_large.hip)
 hipError_t launch_vaat_large(const VaatParams& p, int like, bool exact, hipStream_t stream);
+hipError_t launch_vaat_large_user(const VaatParams& p, bool exact, hipStream_t stream);   // smcmc_user_large.hip
 
 }  // namespace smcmc

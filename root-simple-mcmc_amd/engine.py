@@ -548,8 +548,9 @@ class VaatEngine:
     dimension adapted to a 44 % acceptance.  Chain c is the reference chain on the random stream (seed, chain_offset + c)."""
 
     def __init__(self, dim, nchains=1, likelihood=LIKE_ISO_GAUSS, likelihood_params=None, seed=20240607,
-                 chain_offset=0, device=0, stream=None, exact=True):
-        self._lib = _capi.load()
+                 chain_offset=0, device=0, stream=None, exact=True, library=None):
+        # library: path of a build that carries a user likelihood (LIKE_USER), see build.py --user-likelihood
+        self._lib = _capi.load(library)
         self.dim, self.nchains = int(dim), int(nchains)
         h = C.c_void_p()
         st = self._lib.smcmc_vaat_create(self.dim, self.nchains, likelihood, seed, chain_offset, device, C.byref(h))

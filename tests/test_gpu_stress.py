@@ -79,7 +79,7 @@ def test_stress_likelihoods_pooled_small_dimensions(gpu, oracle, kind, dim, exac
 
 
 @pytest.mark.parametrize("mode", ["frozen", "pooled"])
-@pytest.mark.parametrize("kind,dim", [(ASYM, 100), (HORRIFIC, 75), (ASYM, 300)])
+@pytest.mark.parametrize("kind,dim", [(ASYM, 100), (HORRIFIC, 75), (ASYM, 300), (CONSTRAINED, 100), (CONSTRAINED, 260)])
 def test_stress_likelihoods_reference_dimensions(gpu, oracle, kind, dim, mode):
     """The dimensions the reference's headers fix (100 and 75): the large-dimension kernel, reference order."""
     n = 128
@@ -107,9 +107,10 @@ def test_stress_likelihoods_unsupported_corners(gpu):
     with pytest.raises(gpu.SmcmcError) as err:
         e.Step(1)
     assert err.value.status == 5   # SMCMC_ERR_UNSUPPORTED
-    # per-dimension parameters: dim <= 63
+    e = gpu.Engine(64, 64, likelihood=CONSTRAINED, likelihood_params=np.ones(2 + 2 * 64), exact=False)
+    assert e.Start(np.zeros(64))
     with pytest.raises(gpu.SmcmcError) as err:
-        gpu.Engine(64, 64, likelihood=CONSTRAINED)
+        e.Step(1)
     assert err.value.status == 5   # SMCMC_ERR_UNSUPPORTED
     # wrong parameter count
     with pytest.raises(gpu.SmcmcError):

@@ -62,7 +62,7 @@ def test_vaat_small_dimensions(gpu, oracle, kind, dim, exact):
 
 
 @pytest.mark.parametrize("exact", [True, False])
-@pytest.mark.parametrize("kind,dim", [(0, 64), (1, 100), (2, 200), (4, 100), (5, 75), (0, 500)])
+@pytest.mark.parametrize("kind,dim", [(0, 64), (1, 100), (2, 200), (4, 100), (5, 75), (0, 500), (6, 100)])
 def test_vaat_large_dimensions(gpu, oracle, kind, dim, exact):
     """dim = 100 with the header-form TDummyLogLikelihood is SimpleVAAT.C's own configuration."""
     n = 70
@@ -176,7 +176,7 @@ def test_vaat_posterior_known_answer(gpu):
 
 def test_vaat_unsupported_and_invalid(gpu):
     with pytest.raises(gpu.SmcmcError) as err:
-        gpu.VaatEngine(64, 64, likelihood=6)                                   # CONSTRAINED: dim <= 63
+        gpu.VaatEngine(64, 64, likelihood=3)                                   # USER: not in the plain library
     assert err.value.status == 5
     with pytest.raises(gpu.SmcmcError) as err:
         gpu.VaatEngine(600, 64)

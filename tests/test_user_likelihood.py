@@ -61,11 +61,66 @@ def test_asymmetric_user_likelihood_runs_in_the_step_kernel(gpu, mode):
 @pytest.mark.gpu
 def test_user_likelihood_limits(gpu):
     with pytest.raises(gpu.SmcmcError) as err:
-        gpu.Engine(100, 64, likelihood=gpu.LIKE_USER, library=_user_lib(gpu))      # dim <= 63 only
+        gpu.Engine(600, 64, likelihood=gpu.LIKE_USER, library=_user_lib(gpu))      # dim <= 512
+    assert err.value.status == 5
+    e = gpu.Engine(100, 64, likelihood=gpu.LIKE_USER, likelihood_params=np.array([-1.0, 100.0]), library=_user_lib(gpu),
+                   exact=False)
+    assert e.Start(np.full(100, 0.5))
+    with pytest.raises(gpu.SmcmcError) as err:
+        e.Step(1)                                                                   # dim > 63: reference order only
     assert err.value.status == 5
     with pytest.raises(gpu.SmcmcError) as err:
         gpu.Engine(5, 64, likelihood=gpu.LIKE_USER)                                 # the plain library has none
     assert err.value.status == 5
+
+
+def _lanes_equal(a, b, names):
+    for name in names:
+        assert np.array_equal(a.lane(name), b.lane(name)), name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["frozen", "pooled"])
+@pytest.mark.parametrize("dim", [100, 300])
+def test_user_likelihood_above_63_dimensions(gpu, dim, mode):
+    """smcmc_user_loglike_at (the point read from its [dim][chain] image) in the large-dimension kernel: the example is
+    the library's own ASYM likelihood written as user code, so the two engines must agree bit for bit."""
+    n = 192
+    slopes = np.array([-1.0, 100.0])
+    m = gpu.MODE_FROZEN if mode == "frozen" else gpu.MODE_POOLED
+    u = gpu.Engine(dim, n, likelihood=gpu.LIKE_USER, likelihood_params=slopes, library=_user_lib(gpu), mode=m, seed=9)
+    b = gpu.Engine(dim, n, likelihood=gpu.LIKE_ASYM, likelihood_params=slopes, mode=m, seed=9)
+    x0 = np.random.default_rng(dim).normal(0.3, 0.2, size=(dim, n))
+    assert u.Start(x0) and b.Start(x0)
+    names = ("logl", "sigma", "acceptance", "step_rms", "logl_proposed", "trials", "successes", "naccept")
+    _lanes_equal(u, b, names)
+    for w in range(3):
+        u.Step(10); b.Step(10)
+        if mode == "pooled":
+            u.sync(); b.sync()
+        assert np.array_equal(u.GetAccepted(), b.GetAccepted()), f"window {w}"
+        _lanes_equal(u, b, names)
+    assert u.lane("naccept").sum() > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("exact", [True, False])
+@pytest.mark.parametrize("dim", [10, 40, 100])
+def test_user_likelihood_in_the_variable_at_a_time_chains(gpu, dim, exact):
+    n = 130
+    slopes = np.array([-1.0, 100.0])
+    u = gpu.VaatEngine(dim, n, likelihood=gpu.LIKE_USER, likelihood_params=slopes, library=_user_lib(gpu), seed=4, exact=exact)
+    b = gpu.VaatEngine(dim, n, likelihood=gpu.LIKE_ASYM, likelihood_params=slopes, seed=4, exact=exact)
+    x0 = np.random.default_rng(dim).uniform(-1.0, 1.0, size=(dim, n))
+    assert u.Start(x0) and b.Start(x0)
+    u.UpdateProposal(); b.UpdateProposal()
+    for chunk in (1, dim, dim + 3):
+        u.Step(chunk); b.Step(chunk)
+        assert np.array_equal(u.GetAccepted(), b.GetAccepted())
+        _lanes_equal(u, b, ("logl", "logl_proposed", "step_rms", "trials", "successes", "naccept", "last_index"))
+        for name in ("sigma", "acceptance", "acceptance_trials"):
+            assert np.array_equal(u.per_dim(name), b.per_dim(name)), name
+    assert u.lane("naccept").sum() > 0
 
 
 @pytest.mark.gpu

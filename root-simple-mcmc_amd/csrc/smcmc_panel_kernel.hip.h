@@ -234,11 +234,11 @@ __global__ void __launch_bounds__(W * kWave) panel_step_kernel(const PanelParams
             const int j = jl * W + w;
             xp[jl] = (j < D) ? xsrc[(size_t)j * (W == 4 ? NPl : NP) + chain] : 0.0;
         }
-        uint32_t uword = 0;
         if (no_update && w == 0) {
             smcmc_u32x4 blk = smcmc_draw_block(p.seed, gid, step, aw >> 2, SMCMC_STREAM_STEP);
             verdict_logl[lane] = smcmc_u01(smcmc_select_word(blk, aw & 3u));
         }
+        const int ncols = (D - w + W - 1) / W;   // local columns of this wavefront that exist (j = jl * W + w < D)
         for (int pn = 0; pn < (no_update ? 0 : npanels); ++pn) {
             const int i0 = pn * kPanelRows;
             __syncthreads();                       // the previous panel has been consumed
@@ -262,7 +262,18 @@ __global__ void __launch_bounds__(W * kWave) panel_step_kernel(const PanelParams
                 const f64x2* src = (const f64x2*)(p.Uperm + ((size_t)w * D + i0) * CW);
                 f64x2* dst = (f64x2*)(ulds + w * (kPanelRows * CW));
                 const int npieces = (i1 - i0) * (CW / 2);
-                for (int k = lane; k < npieces; k += kWave) dst[k] = src[k];
+                // eight loads in flight per lane: one at a time, each waits out an L2 round trip before its LDS store
+                // (16 round trips per panel, 16 panels per step, nothing else running on the CU behind the barriers)
+                constexpr int kInFlight = 8;
+                for (int k0 = lane; k0 < npieces; k0 += kInFlight * kWave) {
+                    f64x2 t[kInFlight];
+#pragma unroll
+                    for (int u = 0; u < kInFlight; ++u)
+                        if (k0 + u * kWave < npieces) t[u] = src[k0 + u * kWave];
+#pragma unroll
+                    for (int u = 0; u < kInFlight; ++u)
+                        if (k0 + u * kWave < npieces) dst[k0 + u * kWave] = t[u];
+                }
             }
             __syncthreads();
             lds_cptr_f64 up = (lds_cptr_f64)(ulds + w * (kPanelRows * CW));
@@ -274,7 +285,7 @@ __global__ void __launch_bounds__(W * kWave) panel_step_kernel(const PanelParams
                 lds_cptr_f64 urow = up + (i - i0) * CW;
 #pragma unroll
                 for (int c = 0; c < CW; c += 16) {
-                    if (c + 15 >= jl0) {
+                    if (c + 15 >= jl0 && c < ncols) {
                         // 16 columns: eight broadcast 128-bit LDS reads, kept next to their use
                         f64x2 u2[8];
 #pragma unroll
@@ -377,17 +388,25 @@ __global__ void __launch_bounds__(W * kWave) panel_step_kernel(const PanelParams
                 }
             }
         };
-        for (int g = 0; g < ngather; ++g) {
+        for (int g = 0; g < ngather && g * kGatherJl * W < D; ++g) {
             __syncthreads();
             static_for<ngather>([&](auto gc) { if (g == decltype(gc)::value) write_panel(gc); });
             __syncthreads();
             if (w == 0) {
                 for (int q = 0; q < kGatherJl; ++q) {
+                    // the W values of this local column are read before the (serial) sums consume them
+                    double pjs[W], djs[W];
+#pragma unroll
+                    for (int ww = 0; ww < W; ++ww) {
+                        pjs[ww] = ulds[(q * W + ww) * kWave + lane];
+                        djs[ww] = ulds[kGd + (q * W + ww) * kWave + lane];
+                    }
+#pragma unroll
                     for (int ww = 0; ww < W; ++ww) {
                         const int j = (g * kGatherJl + q) * W + ww;
                         if (j < D) {
-                            const double pj = ulds[(q * W + ww) * kWave + lane];
-                            const double dj = ulds[kGd + (q * W + ww) * kWave + lane];
+                            const double pj = pjs[ww];
+                            const double dj = djs[ww];
                             if constexpr (EXACT) sqr += dj * dj;                     // :393-396
                             else sqr = SMCMC_FMA(dj, dj, sqr);
                             if constexpr (LIKE == SMCMC_LIKE_ISO_GAUSS) {

@@ -122,6 +122,28 @@ __global__ void __launch_bounds__(kPmW* kWave, 1) panel_mfma_kernel(const PanelP
         __syncthreads();
     };
 
+    // one lane per chain walks qs[i][chain], i = 0 .. n-1, in order: sixteen LDS reads are issued ahead of the sixteen
+    // (serially dependent) sums that consume them -- read one at a time, each sum waited out an LDS round trip and the seven
+    // other wavefronts of the workgroup waited with it (a third of the step at D = 500)
+    auto ordered_walk = [&](int n, auto&& f) {
+        int i0 = 0;
+        double v[16], vn[16];
+        if (n >= 16) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = qs[u * kPmCT + lane];
+        }
+        for (; i0 + 16 <= n; i0 += 16) {
+            const int nx = (i0 + 32 <= n) ? i0 + 16 : i0;   // the next full chunk (or this one again: a harmless re-read)
+#pragma unroll
+            for (int u = 0; u < 16; ++u) vn[u] = qs[(nx + u) * kPmCT + lane];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) f(i0 + u, v[u]);
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = vn[u];
+        }
+        for (; i0 < n; ++i0) f(i0, qs[i0 * kPmCT + lane]);
+    };
+
     // per-chain scalar state (summing lanes)
     double logl = 0, sigma = 0, acc_rate = 0, acc_trials = 0, rigid = 0, last_value = 0, last_x0 = 0, step_rms = 0,
            logl_prop = 0;
@@ -192,7 +214,7 @@ __global__ void __launch_bounds__(kPmW* kWave, 1) panel_mfma_kernel(const PanelP
             quadform_terms(x);
             if (summer) {
                 double usum = 0.0;
-                for (int i = 0; i < D; ++i) usum += qs[i * kPmCT + lane];
+                ordered_walk(D, [&](int, double v) { usum += v; });
                 if (active) p.lane_f64[SMCMC_LANE_LOGL * NP + mychain] = -usum;
             }
         }
@@ -319,11 +341,7 @@ __global__ void __launch_bounds__(kPmW* kWave, 1) panel_mfma_kernel(const PanelP
         double sqr = 0.0;
         if (p.step_rms_window > 0) {
             publish([&](int t, int ct, int r) { return xp[t][ct][r] - x[t][ct][r]; });
-            if (summer)
-                for (int i = 0; i < D; ++i) {
-                    const double d = qs[i * kPmCT + lane];
-                    sqr = SMCMC_FMA(d, d, sqr);
-                }
+            if (summer) ordered_walk(D, [&](int, double d) { sqr = SMCMC_FMA(d, d, sqr); });
         }
         // ---- likelihood of the proposal (:410), dimension order ----
         publish([&](int t, int ct, int r) { return xp[t][ct][r]; });
@@ -334,23 +352,21 @@ __global__ void __launch_bounds__(kPmW* kWave, 1) panel_mfma_kernel(const PanelP
             double lsum = 0.0;
             if constexpr (LIKE == SMCMC_LIKE_QUADFORM) {
                 double usum = 0.0;
-                for (int i = 0; i < D; ++i) usum += qs[i * kPmCT + lane];
+                ordered_walk(D, [&](int, double v) { usum += v; });
                 lsum = -usum;
             } else if constexpr (LIKE == SMCMC_LIKE_ISO_GAUSS) {
-                for (int i = 0; i < D; ++i) {
-                    const double pi = qs[i * kPmCT + lane];
-                    lsum = SMCMC_FMA(-0.5 * pi, pi, lsum);
-                }
+                ordered_walk(D, [&](int, double pi) { lsum = SMCMC_FMA(-0.5 * pi, pi, lsum); });
             } else {
-                double prev = qs[lane];
-                for (int i = 0; i < D - 1; ++i) {
-                    const double nx = qs[(i + 1) * kPmCT + lane];
-                    const double a = 1.0 - prev;
-                    const double b = SMCMC_FMA(-prev, prev, nx);
-                    const double tt = SMCMC_FMA(rb * b, b, a * a);
-                    lsum -= tt;
+                double prev = 0.0;
+                ordered_walk(D, [&](int i, double nx) {
+                    if (i > 0) {
+                        const double a = 1.0 - prev;
+                        const double b = SMCMC_FMA(-prev, prev, nx);
+                        const double tt = SMCMC_FMA(rb * b, b, a * a);
+                        lsum -= tt;
+                    }
                     prev = nx;
-                }
+                });
             }
             if (p.step_rms_window > 0) {
                 double ms = step_rms * step_rms;
@@ -429,6 +445,7 @@ __global__ void __launch_bounds__(kPmW* kWave, 1) panel_mfma_kernel(const PanelP
             if (active) p.save_logl[sl * NP + mychain] = logl;
         }
     }
+
 
 #pragma unroll
     for (int t = 0; t < TI; ++t)

@@ -122,24 +122,28 @@ __global__ void __launch_bounds__(kPmW* kWave, 1) panel_mfma_kernel(const PanelP
         __syncthreads();
     };
 
-    // one lane per chain walks qs[i][chain], i = 0 .. n-1, in order: sixteen LDS reads are issued ahead of the sixteen
-    // (serially dependent) sums that consume them -- read one at a time, each sum waited out an LDS round trip and the seven
-    // other wavefronts of the workgroup waited with it (a third of the step at D = 500)
+    // one lane per chain walks qs[i][chain], i = 0 .. n-1, in order: the LDS reads of a few components are issued ahead of the
+    // (serially dependent) sums that consume them, the next few are in flight meanwhile -- read one at a time, each sum waited
+    // out an LDS round trip and the seven other wavefronts of the workgroup waited with it (a third of the step at D = 500).
+    // How far ahead is a register question: at TI = 4 sixteen ahead doubled the spills (93 VGPRs) and the in-launch save of
+    // every step, which reads the spilled point back, went from free to +100 us per step; four ahead spills what the plain
+    // loop did (45) and is as fast in the walk.
     auto ordered_walk = [&](int n, auto&& f) {
+        constexpr int kAhead = (TI >= 4) ? 4 : 8;
         int i0 = 0;
-        double v[16], vn[16];
-        if (n >= 16) {
+        double v[kAhead], vn[kAhead];
+        if (n >= kAhead) {
 #pragma unroll
-            for (int u = 0; u < 16; ++u) v[u] = qs[u * kPmCT + lane];
+            for (int u = 0; u < kAhead; ++u) v[u] = qs[u * kPmCT + lane];
         }
-        for (; i0 + 16 <= n; i0 += 16) {
-            const int nx = (i0 + 32 <= n) ? i0 + 16 : i0;   // the next full chunk (or this one again: a harmless re-read)
+        for (; i0 + kAhead <= n; i0 += kAhead) {
+            const int nx = (i0 + 2 * kAhead <= n) ? i0 + kAhead : i0;   // the next full chunk (or this one again: a harmless re-read)
 #pragma unroll
-            for (int u = 0; u < 16; ++u) vn[u] = qs[(nx + u) * kPmCT + lane];
+            for (int u = 0; u < kAhead; ++u) vn[u] = qs[(nx + u) * kPmCT + lane];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) f(i0 + u, v[u]);
+            for (int u = 0; u < kAhead; ++u) f(i0 + u, v[u]);
 #pragma unroll
-            for (int u = 0; u < 16; ++u) v[u] = vn[u];
+            for (int u = 0; u < kAhead; ++u) v[u] = vn[u];
         }
         for (; i0 < n; ++i0) f(i0, qs[i0 * kPmCT + lane]);
     };

@@ -173,7 +173,17 @@ __global__ void __launch_bounds__(W * kWave) hmc_step_kernel(const HmcParams p) 
                 const f64x2* src = (const f64x2*)(Mperm + ((size_t)w * D + j0) * CW);
                 f64x2* dst = (f64x2*)(ulds + w * (kPanelRows * CW));
                 const int npieces = (j1 - j0) * (CW / 2);
-                for (int k = lane; k < npieces; k += kWave) dst[k] = src[k];
+                // eight loads in flight per lane (one at a time, each waits out an L2 round trip before its LDS store)
+                constexpr int kInFlight = 8;
+                for (int k0 = lane; k0 < npieces; k0 += kInFlight * kWave) {
+                    f64x2 t[kInFlight];
+#pragma unroll
+                    for (int u = 0; u < kInFlight; ++u)
+                        if (k0 + u * kWave < npieces) t[u] = src[k0 + u * kWave];
+#pragma unroll
+                    for (int u = 0; u < kInFlight; ++u)
+                        if (k0 + u * kWave < npieces) dst[k0 + u * kWave] = t[u];
+                }
             }
             __syncthreads();
             lds_cptr_f64 up = (lds_cptr_f64)(ulds + w * (kPanelRows * CW));

@@ -94,10 +94,29 @@ __global__ void __launch_bounds__(kMfW* kWave, 1) hmc_mfma_kernel(const HmcParam
         __syncthreads();
     };
     // sum of the published column of every chain, components in ascending order (one lane per chain)
+    // (eight LDS reads are issued ahead of the eight serially dependent additions that consume them, the next eight in flight
+    // meanwhile: read one at a time, every addition waited out an LDS round trip while seven wavefronts sat at the barrier)
     auto ordered_sum = [&]() {
         double s = 0.0;
-        if (summer)
-            for (int i = 0; i < D; ++i) s += qs[i * kMfCT + lane];
+        if (summer) {
+            constexpr int kAhead = 8;
+            int i0 = 0;
+            double v[kAhead], vn[kAhead];
+            if (D >= kAhead) {
+#pragma unroll
+                for (int u = 0; u < kAhead; ++u) v[u] = qs[u * kMfCT + lane];
+            }
+            for (; i0 + kAhead <= D; i0 += kAhead) {
+                const int nx = (i0 + 2 * kAhead <= D) ? i0 + kAhead : i0;   // (or this chunk again: a harmless re-read)
+#pragma unroll
+                for (int u = 0; u < kAhead; ++u) vn[u] = qs[(nx + u) * kMfCT + lane];
+#pragma unroll
+                for (int u = 0; u < kAhead; ++u) s += v[u];
+#pragma unroll
+                for (int u = 0; u < kAhead; ++u) v[u] = vn[u];
+            }
+            for (; i0 < D; ++i0) s += qs[i0 * kMfCT + lane];
+        }
         return s;
     };
 

@@ -25,6 +25,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "smcmc.h"
 #include "smcmc_detmath.h"
 #include "smcmc_kernels.hip.h"
@@ -375,22 +377,42 @@ __global__ void __launch_bounds__(W * kWave) panel_step_kernel(const PanelParams
         const double rb = (LIKE == SMCMC_LIKE_ROSENBROCK) ? likep[0] : 0.0;
         // xp[] must be indexed statically to stay in registers: the panel number selects one of
         // `ngather` fully unrolled write blocks; the (long) serial walk below is emitted once
-        auto write_panel = [&](auto gc) {
+        // the accepted point's values for a gather round are loaded one round ahead: the second read of the state came in a
+        // burst from every CU at once (a tenth of the step), now it is in flight while wavefront 0 walks the previous round
+        double xv[kGatherJl];
+        auto load_x = [&](auto gc) {
             constexpr int g = decltype(gc)::value;
 #pragma unroll
             for (int q = 0; q < kGatherJl; ++q) {
                 const int jl = g * kGatherJl + q;
                 if (jl < CW) {
                     const int j = jl * W + w;
-                    const double xv = (j < D) ? p.x[(size_t)j * (W == 4 ? NPl : NP) + chain] : 0.0;
-                    ulds[(q * W + w) * kWave + lane] = xp[jl];
-                    ulds[kGd + (q * W + w) * kWave + lane] = xp[jl] - xv;
+                    xv[q] = (j < D) ? p.x[(size_t)j * (W == 4 ? NPl : NP) + chain] : 0.0;
                 }
             }
         };
+        auto write_panel = [&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+#pragma unroll
+            for (int q = 0; q < kGatherJl; ++q) {
+                const int jl = g * kGatherJl + q;
+                if (jl < CW) {
+                    ulds[(q * W + w) * kWave + lane] = xp[jl];
+                    ulds[kGd + (q * W + w) * kWave + lane] = xp[jl] - xv[q];
+                }
+            }
+        };
+        load_x(std::integral_constant<int, 0>{});
         for (int g = 0; g < ngather && g * kGatherJl * W < D; ++g) {
             __syncthreads();
-            static_for<ngather>([&](auto gc) { if (g == decltype(gc)::value) write_panel(gc); });
+            static_for<ngather>([&](auto gc) {
+                if (g == decltype(gc)::value) {
+                    write_panel(gc);
+                    if constexpr (decltype(gc)::value + 1 < ngather) {
+                        if ((g + 1) * kGatherJl * W < D) load_x(std::integral_constant<int, decltype(gc)::value + 1>{});
+                    }
+                }
+            });
             __syncthreads();
             if (w == 0) {
                 for (int q = 0; q < kGatherJl; ++q) {

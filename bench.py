@@ -204,23 +204,42 @@ def main():
     ap.add_argument("--dim", type=int, default=DIM, help="diagnostic: other dimension (not the headline)")
     ap.add_argument("--header-tdummy", action="store_true",
                     help="diagnostic: the headline loop on the other C2 likelihood (header-form TDummyLogLikelihood)")
+    ap.add_argument("--native-comm", action="store_true",
+                    help="N > 1: the moment all-reduce through the library's own RCCL communicator (smcmc_comm_init / "
+                         "smcmc_allreduce_moments, the C / C++ callers' path) instead of torch.distributed")
     args = ap.parse_args()
 
     import torch
-    import torch.distributed as dist
     from smcmc_amd_loader import load_package
     pkg = load_package()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` as typed: this process becomes the launcher of N rank processes, one per GPU, and
+        # stays off the GPU itself (counting devices does not create a HIP context; nothing else here touches it)
+        try:
+            code, out = pkg.distributed.launch_local_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+                                                           args.gpus, torch.cuda.device_count())
+        except RuntimeError as exc:
+            raise SystemExit("bench.py --gpus %d: %s" % (args.gpus, exc))
+        sys.stdout.write(out)
+        sys.stdout.flush()
+        raise SystemExit(code)
+
+    import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: start one rank per GPU (torch.distributed.run --nproc-per-node N), "
+                         "or unset WORLD_SIZE and let bench.py launch them" % (args.gpus, world))
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if args.native_comm:
+            # rendezvous, barrier and the max-over-ranks of the timing only (CPU, gloo): the data path is the library's
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
     stream = torch.cuda.current_stream()
     dim = args.dim
@@ -235,7 +254,12 @@ def main():
 
     # the window loop is the package's own (distributed.run_windows): steps, moment reduction, all-reduce over the
     # ranks when there are several, pooled update; the backend times the step launches with HIP events on its stream
-    backend = pkg.distributed.HipBackend(eng, frozen=args.frozen, time_steps=True, stream=stream)
+    if world > 1 and args.native_comm:
+        ident = [pkg.Engine.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ident, src=0)
+        backend = pkg.distributed.NativeBackend(eng, rank, world, ident[0], frozen=args.frozen, time_steps=True, stream=stream)
+    else:
+        backend = pkg.distributed.HipBackend(eng, frozen=args.frozen, time_steps=True, stream=stream)
 
     def fence():
         torch.cuda.synchronize()
@@ -245,6 +269,7 @@ def main():
 
     pkg.distributed.run_windows(backend, args.warmup, args.window)
     backend.events.clear()
+    backend.comm_events.clear()
     gc.collect(); gc.disable()    # no collector pauses inside the timed region
     fence()
     t0 = time.perf_counter()
@@ -252,10 +277,14 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     gc.enable()
+    rccl_ranks = 1
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.native_comm else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        # the size of the communicator the moments crossed: the library's own (ncclCommCount) or torch's RCCL group
+        rccl_ranks = eng.comm_ranks() if args.native_comm else dist.get_world_size()
+    ms_allreduce = (float(np.mean([a.elapsed_time(b) for a, b in backend.comm_events])) if backend.comm_events else None)
 
     chain_steps = float(args.chains) * world * args.window * args.steps
     value = chain_steps / dt
@@ -292,6 +321,9 @@ def main():
         "metric": "chain-steps/s on D=50 TDummyLogLikelihood, 65 536 chains; ESS/s + accept rate",
         "value": value, "unit": "chain-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "rccl_ranks": rccl_ranks, "ms_allreduce": ms_allreduce,
+        "comm": ("none (one rank)" if world == 1 else "library RCCL communicator (smcmc_comm_init / smcmc_allreduce_moments)"
+                 if args.native_comm else "torch.distributed nccl (= RCCL)"),
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": ("TDummyLogLikelihood header form (quadratic form)" if args.header_tdummy else
                                 "TDummyLogLikelihood README form (iso-Gaussian)") +

@@ -66,8 +66,16 @@ typedef enum {
 typedef enum {
     SMCMC_MODE_FROZEN = 0,  /* SetCovarianceFrozen(true) (TSimpleMCMC.H:937): every chain is an
                                independent reference chain on the shared, fixed decomposition */
-    SMCMC_MODE_POOLED = 1   /* running centre/covariance (TSimpleMCMC.H:1780-1820) pooled over all
+    SMCMC_MODE_POOLED = 1,  /* running centre/covariance (TSimpleMCMC.H:1780-1820) pooled over all
                                chains through batch moments; UpdateProposal at every smcmc_sync */
+    SMCMC_MODE_PER_CHAIN = 2 /* the reference's own mode, per chain: every chain keeps its own centre, covariance and
+                               decomposition ([k][chain] columns in device memory), runs UpdateState every step
+                               (:1721-1831, the covariance loop of :1795-1820 included) and UpdateProposal when its own
+                               --fNextUpdate < 1 on an accepted step (:1824-1826).  Every chain is bit for bit the
+                               reference chain on its random stream.  dim <= 63, reference-order arithmetic, Gaussian
+                               proposals in every dimension; memory 12 dim (dim + 1) + 32 dim bytes per chain.
+                               The shared getters (centre, covariance, decomposition, trials, trace) answer for
+                               chain 0, the setters act on every chain; smcmc_read_chain_proposal reads any chain. */
 } smcmc_mode;
 
 /* Scalar knobs / observables of TProposeAdaptiveStep and TSimpleMCMC. */
@@ -100,6 +108,8 @@ typedef enum {
     SMCMC_P_OVERLAP_UPDATE = 22,        /* 1: the next launch does not wait for the status of the update before it;
                                          * identical results unless that update falls back to the ladder, which then takes effect one
                                          * window late.  0 (default): parity mode */
+    SMCMC_P_COVARIANCE_FROZEN = 23,     /* Set/GetCovarianceFrozen :937-938 inside SMCMC_MODE_PER_CHAIN: the covariance loop is
+                                         * skipped, the centre still runs (SMCMC_MODE_FROZEN is the shared-decomposition form) */
     SMCMC_P_COUNT_
 } smcmc_param;
 
@@ -114,6 +124,10 @@ typedef enum {
     SMCMC_LANE_LAST_X0 = 6,         /* fLastPoint[0]           :1835 */
     SMCMC_LANE_STEP_RMS = 7,        /* fStepRMS                :580 */
     SMCMC_LANE_LOGL_PROPOSED = 8,   /* fProposedLogLikelihood  :589 */
+    /* SMCMC_MODE_PER_CHAIN only */
+    SMCMC_LANE_CENTER_TRIALS = 9,   /* fCentralPointTrials     :1849 */
+    SMCMC_LANE_COVARIANCE_TRIALS = 10, /* fCovarianceTrials    :1867 */
+    SMCMC_LANE_SIGMA_TRACE = 11,    /* fSigmaTrace             :1960 */
     SMCMC_LANE_F64_COUNT_
 } smcmc_lane_f64;
 
@@ -125,6 +139,12 @@ typedef enum {
     SMCMC_LANE_NACCEPT = 3,         /* sum of Step() return values */
     SMCMC_LANE_STEP_RMS_TRIALS = 4, /* fStepRMSTrials :583 */
     SMCMC_LANE_LAST_ACCEPT = 5,     /* Step() return value of the latest step */
+    /* SMCMC_MODE_PER_CHAIN only */
+    SMCMC_LANE_UPDATE_STATUS = 6,   /* 0 between calls (inside a launch: a chain waiting for the host's fallback ladder) */
+    SMCMC_LANE_DECOMP_FULL = 7,     /* 1: fDecomposition is a full matrix (the eigen rung of the ladder, :1252-1321) */
+    SMCMC_LANE_CHAIN_STEPS = 8,     /* fTotalSteps :554 of the chain */
+    SMCMC_LANE_UPDATE_COUNT = 9,    /* UpdateProposal calls of the chain (diagnostic) */
+    SMCMC_LANE_LAST_UPDATE_PATH = 10, /* rung of the latest UpdateProposal: 0 Cholesky 1 conditioned 2 eigen 3 emergency 4 reset */
     SMCMC_LANE_I32_COUNT_
 } smcmc_lane_i32;
 
@@ -225,6 +245,7 @@ int smcmc_sync(smcmc_engine* h);
 int smcmc_comm_unique_id(void* id_out);
 int smcmc_comm_init(smcmc_engine* h, const void* id, int rank, int nranks);
 int smcmc_comm_destroy(smcmc_engine* h);
+int smcmc_comm_ranks(smcmc_engine* h);         /* ncclCommCount of the attached communicator; 0 without one, < 0 on error */
 int smcmc_allreduce_moments(smcmc_engine* h);
 int smcmc_update_proposal(smcmc_engine* h);   /* UpdateProposal() :1009 on the shared proposal */
 int smcmc_reset_proposal(smcmc_engine* h);    /* ResetProposal()  :1396 */
@@ -244,6 +265,14 @@ int smcmc_set_center(smcmc_engine* h, const double* in);  /* SetEstimatedCenter 
 int smcmc_get_covariance(smcmc_engine* h, double* out);   /* fCurrentCov, dim*dim */
 int smcmc_set_covariance(smcmc_engine* h, const double* in);
 int smcmc_get_decomposition(smcmc_engine* h, double* out);/* fDecomposition, dim*dim */
+/* One chain's members, as the host mirror of the reference class keeps them for chain 0 after every Step(): any
+ * pointer may be NULL.  x[dim] = fAccepted; proposed[dim] = fProposed (needs SMCMC_P_KEEP_PROPOSED outside
+ * SMCMC_MODE_PER_CHAIN, which always keeps it); lanes_f64[SMCMC_LANE_F64_COUNT_], lanes_i32[SMCMC_LANE_I32_COUNT_]. */
+int smcmc_read_chain(smcmc_engine* h, int chain, double* x, double* proposed, double* lanes_f64, int32_t* lanes_i32);
+/* SMCMC_MODE_PER_CHAIN: the adaptive state of one chain -- fCentralPoint [dim], fCurrentCov [dim*dim],
+ * fDecomposition [dim*dim] (TSimpleMCMC.H:1841-1893); any pointer may be NULL.  In the other modes the shared
+ * proposal's (the same for every chain). */
+int smcmc_read_chain_proposal(smcmc_engine* h, int chain, double* centre, double* covariance, double* decomposition);
 /* device pointers for zero-copy consumers (x: [dim_padded][nchains_padded], logl: [nchains_padded]) */
 int smcmc_state_device_ptr(smcmc_engine* h, double** x, double** logl);
 

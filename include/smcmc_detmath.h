@@ -1,4 +1,4 @@
-/* smcmc_detmath.h -- deterministic scalar math + Philox4x32-10 shared by the
+/* smcmc_detmath.h -- deterministic scalar math + Philox4x32 shared by the
  * HIP kernels (device), the C++ host layer and the CPU oracle.
  *
  * Why this exists: the hot path needs log (Metropolis test, reference
@@ -68,6 +68,27 @@ SMCMC_HD double smcmc_u2d(uint64_t x) {
 
 typedef struct { uint32_t v[4]; } smcmc_u32x4;
 
+/* `rounds` rounds of Philox4x32 starting at round `first` of the key schedule (first = 0 for a whole generator; the
+ * tests continue a 7-round block by three more rounds, first = 7, and compare with the 10-round known answers). */
+SMCMC_HD smcmc_u32x4 smcmc_philox4x32_rounds(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                             uint32_t k1, int first, int rounds) {
+    k0 += (uint32_t)first * SMCMC_PHILOX_W0;
+    k1 += (uint32_t)first * SMCMC_PHILOX_W1;
+    SMCMC_UNROLL
+    for (int r = 0; r < rounds; ++r) {
+        uint64_t p0 = (uint64_t)SMCMC_PHILOX_M0 * (uint64_t)c0;
+        uint64_t p1 = (uint64_t)SMCMC_PHILOX_M1 * (uint64_t)c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += SMCMC_PHILOX_W0; k1 += SMCMC_PHILOX_W1;
+    }
+    smcmc_u32x4 out; out.v[0] = c0; out.v[1] = c1; out.v[2] = c2; out.v[3] = c3;
+    return out;
+}
+
 SMCMC_HD smcmc_u32x4 smcmc_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2,
                                          uint32_t c3, uint32_t k0, uint32_t k1) {
     SMCMC_UNROLL
@@ -93,11 +114,16 @@ SMCMC_HD smcmc_u32x4 smcmc_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2,
                                  * used), word 2 its Uniform(a,b), word 3 the Metropolis uniform, words 4+i the i-th
                                  * Uniform() of a queue shuffle made during that step (TProposeVAATStep.H:190-193) */
 
+/* Every draw of the engine is a block of Philox4x32-7: seven rounds is the count Salmon et al. (SC'11, table 2) report
+ * as the fewest that pass BigCrush ("Crush-resistant"), ten their default with a safety margin.  The headline kernel
+ * spends 13 blocks per chain-step, so the three rounds are 3 % of its instructions; the round function and the key
+ * schedule are pinned by the Random123 known answers of the 10-round generator (tests/test_detmath.py). */
+#define SMCMC_PHILOX_ROUNDS 7
 SMCMC_HD smcmc_u32x4 smcmc_draw_block(uint64_t seed, uint32_t chain, uint64_t step,
                                       uint32_t block, uint32_t stream) {
-    return smcmc_philox4x32_10(block, chain, (uint32_t)step,
-                               ((uint32_t)(step >> 32) & 0x0FFFFFFFu) | (stream << 28),
-                               (uint32_t)seed, (uint32_t)(seed >> 32));
+    return smcmc_philox4x32_rounds(block, chain, (uint32_t)step,
+                                   ((uint32_t)(step >> 32) & 0x0FFFFFFFu) | (stream << 28),
+                                   (uint32_t)seed, (uint32_t)(seed >> 32), 0, SMCMC_PHILOX_ROUNDS);
 }
 
 /* 32-bit word -> u in (0,1): (w + 0.5) * 2^-32, exact in binary64. */
@@ -287,14 +313,75 @@ SMCMC_HD double smcmc_sqrt_mid(double x) {
 }
 
 /* ---- Box-Muller pair from two 32-bit words -------------------------------
- * n0 = r cos(theta), n1 = r sin(theta), r = sqrt(-2 log u1), theta = 2 pi u2. */
+ * n0 = r cos(theta), n1 = r sin(theta), r = sqrt(-2 log u1), u1 = (w0 + 1/2) 2^-32, theta = 2 pi (w1 + 1/2) 2^-32.
+ *
+ * The transform is the engine's own (the reference draws from ROOT's TRandom::Gaus, an unrelated rejection method):
+ * it has to be one function of the two words on host and device and accurate far below the 2^-32 resolution of its
+ * input, not the textbook libm composition.  Built for instruction count (a lone wavefront per SIMD issues one
+ * instruction per four cycles whatever its type), division free, two 64-entry tables (include/smcmc_normal_tables.h):
+ *   radius  u1 = 2^e m, m in [1, 2); k = top six mantissa bits, t = m r_k - 1 (|t| < 2^-7, r_k = RN(1/c_k));
+ *           -2 ln u1 = (-2 ln 2) e + L_k - 2 log1p(t), L_k = RN(2 ln r_k), log1p by its series to t^6
+ *           (truncation < 3e-16); the square root is the correctly rounded one;
+ *   angle   w1 = q 2^30 + k 2^24 + f: quadrant q, sub-angle theta_k = (k + 1/2) pi / 128 from the table as
+ *           {cos, sin}, the rest delta = (f + 1/2 - 2^23) (pi/2) 2^-30, |delta| < pi / 256, by its series
+ *           (sin to delta^5, cos to delta^6: truncation < 1e-17), one rotation, then the quadrant.
+ * Absolute error of a normal <= ~1e-15 (tests/test_detmath.py compares with the exact formula and checks tails and
+ * moments).  The accept test's logarithm (TSimpleMCMC.H:455) and the sigma update's pow (:1772) keep the <= 1 ulp
+ * functions above.  SMCMC_NORMAL_PAIR_BODY is the function body, so that a kernel with the tables in LDS can
+ * instantiate it with its own loads (smcmc_kernels.hip.h); LT(k, c) / AT(k, c) read component c of entry k. */
+#include "smcmc_normal_tables.h"
+
+#define SMCMC_NORMAL_PAIR_BODY(LT, AT)                                                                                  \
+    /* radius */                                                                                                       \
+    const uint64_t ub_ = smcmc_d2u(smcmc_u01(w0));                                                                      \
+    const uint32_t uh_ = (uint32_t)(ub_ >> 32);                                                                         \
+    const int e_ = (int)(uh_ >> 20) - 1023;                                                                             \
+    const uint32_t lk_ = (uh_ >> 14) & 63u;                                                                             \
+    const double m_ = smcmc_u2d((ub_ & 0x000fffffffffffffull) | 0x3ff0000000000000ull);                                 \
+    const double t_ = SMCMC_FMA(m_, LT(lk_, 0), -1.0);                                                                  \
+    /* -2 log1p(t) = t (-2 + t (1 + t (-2/3 + t (1/2 + t (-2/5 + t/3))))) */                                            \
+    double q_ = SMCMC_FMA(t_, 0x1.5555555555555p-2, -0x1.999999999999ap-2);                                             \
+    q_ = SMCMC_FMA(t_, q_, 0.5);                                                                                        \
+    q_ = SMCMC_FMA(t_, q_, -0x1.5555555555555p-1);                                                                      \
+    q_ = SMCMC_FMA(t_, q_, 1.0);                                                                                        \
+    q_ = SMCMC_FMA(t_, q_, -2.0);                                                                                       \
+    const double s_ = SMCMC_FMA(t_, q_, SMCMC_FMA((double)e_, -0x1.62e42fefa39efp+0, LT(lk_, 1)));                      \
+    const double r_ = smcmc_sqrt_mid(s_);                                                                               \
+    /* angle */                                                                                                        \
+    const uint32_t ak_ = (w1 >> 24) & 63u;                                                                              \
+    const int32_t f_ = (int32_t)(w1 & 0x00ffffffu) - 0x00800000;                                                        \
+    const double d_ = SMCMC_FMA((double)f_, 0x1.921fb54442d18p-30, 0x1.921fb54442d18p-31);   /* (f + 1/2)(pi/2) 2^-30 */ \
+    const double z_ = d_ * d_;                                                                                          \
+    const double sd_ = SMCMC_FMA(d_ * z_, SMCMC_FMA(z_, 0x1.1111111111111p-7, -0x1.5555555555555p-3), d_);              \
+    const double cd_ = SMCMC_FMA(z_, SMCMC_FMA(z_, SMCMC_FMA(z_, -0x1.6c16c16c16c17p-10, 0x1.5555555555555p-5), -0.5), 1.0); \
+    const double ck_ = AT(ak_, 0), sk_ = AT(ak_, 1);                                                                    \
+    const double c_ = SMCMC_FMA(-sk_, sd_, ck_ * cd_);                                                                  \
+    const double sn_ = SMCMC_FMA(ck_, sd_, sk_ * cd_);                                                                  \
+    /* quadrant: q=0 (c,s)  q=1 (-s,c)  q=2 (-c,-s)  q=3 (s,-c) */                                                      \
+    const uint32_t qd_ = w1 >> 30;                                                                                      \
+    const double rc_ = (qd_ & 1u) ? sn_ : c_;                                                                           \
+    const double rs_ = (qd_ & 1u) ? c_ : sn_;                                                                           \
+    const double cs_ = smcmc_u2d(smcmc_d2u(rc_) ^ ((uint64_t)((qd_ + 1u) & 2u) << 62));                                 \
+    const double ss_ = smcmc_u2d(smcmc_d2u(rs_) ^ ((uint64_t)(qd_ & 2u) << 62));                                        \
+    *n0 = r_ * cs_;                                                                                                     \
+    *n1 = r_ * ss_;
+
+static const double smcmc_log_table_host[128] = SMCMC_LOG_TABLE_INIT;
+static const double smcmc_angle_table_host[128] = SMCMC_ANGLE_TABLE_INIT;
+#if defined(__HIPCC__)
+static __device__ const double smcmc_log_table_dev[128] = SMCMC_LOG_TABLE_INIT;
+static __device__ const double smcmc_angle_table_dev[128] = SMCMC_ANGLE_TABLE_INIT;
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SMCMC_LT_DEFAULT(k, c) smcmc_log_table_dev[2u * (k) + (c)]
+#define SMCMC_AT_DEFAULT(k, c) smcmc_angle_table_dev[2u * (k) + (c)]
+#else
+#define SMCMC_LT_DEFAULT(k, c) smcmc_log_table_host[2u * (k) + (c)]
+#define SMCMC_AT_DEFAULT(k, c) smcmc_angle_table_host[2u * (k) + (c)]
+#endif
+
 SMCMC_HD void smcmc_normal_pair(uint32_t w0, uint32_t w1, double* n0, double* n1) {
-    double u1 = smcmc_u01(w0);
-    double r = smcmc_sqrt_mid(-2.0 * smcmc_log_pos(u1));
-    double sn, cs;
-    smcmc_sincos2pi_u32(w1, &sn, &cs);
-    *n0 = r * cs;
-    *n1 = r * sn;
+    SMCMC_NORMAL_PAIR_BODY(SMCMC_LT_DEFAULT, SMCMC_AT_DEFAULT)
 }
 
 /* v[i] for a run-time i without indexing memory. */

@@ -59,6 +59,7 @@ def _declare(L):
         ("set_acceptance_rigidity", [C.c_double]), ("set_target_acceptance", [C.c_double]),
         ("set_next_update", [C.c_double]), ("set_sigma", [C.c_double]),
         ("set_step_rms_window", [C.c_int]), ("set_scan_dimension", [C.c_int]),
+        ("set_covariance_trials", [C.c_double]), ("set_center_trials", [C.c_double]), ("set_covariance", [_dp]),
         ("force_step", [_dp]), ("update_proposal", []), ("reset_proposal", []),
     ]:
         f = getattr(L, "oracle_chain_" + name)
@@ -88,6 +89,9 @@ def _declare(L):
     L.oracle_u01_v.argtypes = [C.c_int, _dp, _dp]
     L.oracle_normal_pair_v.argtypes = [C.c_int, _dp, _dp, _dp, _dp]
     L.oracle_philox.argtypes = [C.c_uint32] * 6 + [C.POINTER(C.c_uint32)]
+    L.oracle_philox_rounds.argtypes = [C.c_uint32] * 6 + [C.c_int, C.c_int, C.POINTER(C.c_uint32)]
+    L.oracle_philox_draw_rounds.restype = C.c_int
+    L.oracle_draw_block.argtypes = [C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
     L.oracle_step_draws.argtypes = [C.c_uint64, C.c_uint32, C.c_uint64, C.c_int, _dp, _dp]
     L.oracle_cholesky.restype = C.c_int
     L.oracle_cholesky.argtypes = [C.c_int, _dp, _dp]
@@ -250,6 +254,11 @@ class Chain:
 
     def force_step(self, p):
         lib().oracle_chain_force_step(self._h, _p(_f64(p)))
+
+    def set_covariance(self, cov):
+        cov = _f64(cov)
+        assert cov.shape == (self.dim, self.dim)
+        lib().oracle_chain_set_covariance(self._h, _p(cov))
 
     def start(self, x0):
         return bool(lib().oracle_chain_start_api(self._h, _p(_f64(x0))))
@@ -439,6 +448,22 @@ def det_normal_pair(w0, w1):
 def philox(ctr, key):
     out = (C.c_uint32 * 4)()
     lib().oracle_philox(*[int(v) for v in ctr], *[int(v) for v in key], out)
+    return [int(v) for v in out]
+
+
+def philox_rounds(ctr, key, first, rounds):
+    out = (C.c_uint32 * 4)()
+    lib().oracle_philox_rounds(*[int(v) for v in ctr], *[int(v) for v in key], int(first), int(rounds), out)
+    return [int(v) for v in out]
+
+
+def philox_draw_rounds():
+    return lib().oracle_philox_draw_rounds()
+
+
+def draw_block(seed, chain, step, block, stream=0):
+    out = (C.c_uint32 * 4)()
+    lib().oracle_draw_block(seed, chain, step, block, stream, out)
     return [int(v) for v in out]
 
 

@@ -73,6 +73,12 @@ void oracle_chain_force_step(oracle_chain* c, const double* p) {            /* :
     memcpy(c->prop.forced, p, sizeof(double) * (size_t)c->dim);
     c->prop.has_forced = 1;
 }
+/* fCurrentCov overwritten (the engine's SetCovariance hook), SetCovarianceTrials :947, SetEstimatedCenterTrials :747 */
+void oracle_chain_set_covariance(oracle_chain* c, const double* cov) {
+    memcpy(c->prop.cov, cov, sizeof(double) * (size_t)c->dim * (size_t)c->dim);
+}
+void oracle_chain_set_covariance_trials(oracle_chain* c, double t) { c->prop.cov_trials = t; }
+void oracle_chain_set_center_trials(oracle_chain* c, double t) { c->prop.central_trials = t; }
 void oracle_chain_update_proposal(oracle_chain* c) { oracle_proposal_update(&c->prop, 0); }
 void oracle_chain_reset_proposal(oracle_chain* c) { oracle_proposal_reset(&c->prop); }
 
@@ -157,6 +163,18 @@ void oracle_sincos2pi_u32_v(int n, const double* w, double* s, double* c) {
 void oracle_u01_v(int n, const double* w, double* out) { for (int i = 0; i < n; ++i) out[i] = smcmc_u01((uint32_t)w[i]); }
 void oracle_normal_pair_v(int n, const double* w0, const double* w1, double* n0, double* n1) {
     for (int i = 0; i < n; ++i) smcmc_normal_pair((uint32_t)w0[i], (uint32_t)w1[i], &n0[i], &n1[i]);
+}
+/* `rounds` rounds starting at round `first` of the key schedule (the engine draws with SMCMC_PHILOX_ROUNDS rounds) */
+void oracle_philox_rounds(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, int first,
+                          int rounds, uint32_t* out) {
+    smcmc_u32x4 r = smcmc_philox4x32_rounds(c0, c1, c2, c3, k0, k1, first, rounds);
+    for (int i = 0; i < 4; ++i) out[i] = r.v[i];
+}
+int oracle_philox_draw_rounds(void) { return SMCMC_PHILOX_ROUNDS; }
+/* the block smcmc_draw_block hands out for (seed, chain, step, block, stream) */
+void oracle_draw_block(uint64_t seed, uint32_t chain, uint64_t step, uint32_t block, uint32_t stream, uint32_t* out) {
+    smcmc_u32x4 r = smcmc_draw_block(seed, chain, step, block, stream);
+    for (int i = 0; i < 4; ++i) out[i] = r.v[i];
 }
 void oracle_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t* out) {
     smcmc_u32x4 r = smcmc_philox4x32_10(c0, c1, c2, c3, k0, k1);

@@ -156,7 +156,7 @@ int oracle_vaat_start(oracle_vaat* e, const double* x0, int broadcast) {
         }
         e->logl[c] = vaat_like(e, p);
         if (!isfinite(e->logl[c]) || e->logl[c] < -0.999999E+10) ok = 0;
-        e->last_value[c] = e->logl[c];                                /* :207 */
+        if (!e->initialized) e->last_value[c] = e->logl[c];           /* :207, behind the early return of :197 */
         e->last_logl_proposed[c] = e->logl[c];
     }
     free(p);

@@ -7,7 +7,7 @@ a hyphen, so import it through the loader at the repo root:
     from smcmc_amd_loader import load_package
     smcmc = load_package()          # module object, registered as "root_simple_mcmc_amd"
 """
-from ._capi import (LIKE_ASYM, LIKE_CONSTRAINED, LIKE_HORRIFIC, LIKE_ISO_GAUSS, LIKE_QUADFORM, LIKE_ROSENBROCK, LIKE_USER, MODE_FROZEN, MODE_POOLED, SmcmcError,  # noqa: F401
+from ._capi import (LIKE_ASYM, LIKE_CONSTRAINED, LIKE_HORRIFIC, LIKE_ISO_GAUSS, LIKE_QUADFORM, LIKE_ROSENBROCK, LIKE_USER, MODE_FROZEN, MODE_PER_CHAIN, MODE_POOLED, SmcmcError,  # noqa: F401
                     LIB_PATH, SIGNATURES, load)
 from .engine import Autocorrelation, Engine, HmcEngine, PosteriorMoments, VaatEngine, selftest_detmath, selftest_mfma, selftest_mfma_strip  # noqa: F401
 from . import build as _build_mod  # noqa: F401

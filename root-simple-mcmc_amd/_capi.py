@@ -14,19 +14,20 @@ OK, ERR_INVALID, ERR_LOGIC, ERR_RUNTIME, ERR_BAD_START, ERR_UNSUPPORTED, ERR_HIP
 
 LIKE_ISO_GAUSS, LIKE_QUADFORM, LIKE_ROSENBROCK, LIKE_USER = 0, 1, 2, 3
 LIKE_ASYM, LIKE_HORRIFIC, LIKE_CONSTRAINED = 4, 5, 6   # the reference's stress targets (smcmc.h)
-MODE_FROZEN, MODE_POOLED = 0, 1
+MODE_FROZEN, MODE_POOLED, MODE_PER_CHAIN = 0, 1, 2
 
 PARAMS = ["COVARIANCE_WINDOW", "COVARIANCE_DEWEIGHT", "ACCEPTANCE_WINDOW", "ACCEPTANCE_DEWEIGHT",
           "ACCEPTANCE_RIGIDITY", "TARGET_ACCEPTANCE", "SIGMA", "MAXIMUM_CORRELATION", "STEP_RMS_WINDOW",
           "NEXT_UPDATE", "COVARIANCE_TRIALS", "CENTER_TRIALS", "COVARIANCE_TRACE", "TOTAL_STEPS",
           "SIGMA_TRACE", "UPDATE_COUNT", "LAST_UPDATE_PATH", "EXACT_ARITHMETIC", "MOMENT_STRIDE", "MOMENT_GROUP", "KEEP_PROPOSED",
-          "DEVICE_UPDATE", "OVERLAP_UPDATE"]
+          "DEVICE_UPDATE", "OVERLAP_UPDATE", "COVARIANCE_FROZEN"]
 P = {name: i for i, name in enumerate(PARAMS)}
 LANE_F64 = {name: i for i, name in enumerate(
     ["logl", "sigma", "acceptance", "acceptance_trials", "rigidity", "last_value", "last_x0", "step_rms",
-     "logl_proposed"])}
+     "logl_proposed", "center_trials", "covariance_trials", "sigma_trace"])}
 LANE_I32 = {name: i for i, name in enumerate(
-    ["trials", "successes", "next_update", "naccept", "step_rms_trials", "last_accept"])}
+    ["trials", "successes", "next_update", "naccept", "step_rms_trials", "last_accept", "update_status", "decomp_full",
+     "chain_steps", "update_count", "last_update_path"])}
 # the HMC engine's aliases (SMCMC_HMC_LANE_* of include/smcmc.h)
 HMC_LANE_F64 = dict(LANE_F64, mean_epsilon=LANE_F64["sigma"], reversal_len=LANE_F64["rigidity"])
 HMC_LANE_I32 = dict(LANE_I32, leapfrog=LANE_I32["next_update"], contributes=LANE_I32["successes"])
@@ -84,6 +85,7 @@ SIGNATURES = {
     "smcmc_comm_unique_id": (C.c_int, [C.c_void_p]),
     "smcmc_comm_init": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_int]),
     "smcmc_comm_destroy": (C.c_int, [_H]),
+    "smcmc_comm_ranks": (C.c_int, [_H]),
     "smcmc_allreduce_moments": (C.c_int, [_H]),
     "smcmc_update_proposal": (C.c_int, [_H]),
     "smcmc_reset_proposal": (C.c_int, [_H]),
@@ -100,6 +102,8 @@ SIGNATURES = {
     "smcmc_set_covariance": (C.c_int, [_H, _dp]),
     "smcmc_get_decomposition": (C.c_int, [_H, _dp]),
     "smcmc_state_device_ptr": (C.c_int, [_H, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "smcmc_read_chain": (C.c_int, [_H, C.c_int, _dp, _dp, _dp, _ip]),
+    "smcmc_read_chain_proposal": (C.c_int, [_H, C.c_int, _dp, _dp, _dp]),
     "smcmc_hmc_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint32, C.c_int, C.POINTER(_H)]),
     "smcmc_hmc_destroy": (C.c_int, [_H]),
     "smcmc_hmc_last_error": (C.c_char_p, [_H]),

@@ -51,7 +51,7 @@ def _units(user_flag=None):
     units = [engine, ("smcmc_selftest.hip", [], "selftest"), ("smcmc_autocorr.hip", [], "autocorr"),
              ("smcmc_hmc_engine.hip", [], "hmc_engine"), ("smcmc_hmc_mfma_inst.hip", [], "hmc_mfma"),
              vaat, ("smcmc_vaat_large.hip", [], "vaat_large"),
-             ("smcmc_pooled_update.hip", [], "pooled_update"),
+             ("smcmc_pooled_update.hip", [], "pooled_update"), ("smcmc_perchain_inst.hip", [], "perchain"),
              ("smcmc_panel_mfma_inst.hip", [], "panel_mfma")]
     for dp in dp_list():
         for like in LIKELIHOODS:
@@ -71,6 +71,7 @@ def _units(user_flag=None):
 
 
 _EXTRA = {"files": []}   # the user likelihood header, part of the stamps of the units built with it
+_STALE = []              # SMCMC_BUILD_ONLY: units linked although their sources changed
 
 
 def _closure(path, seen):
@@ -92,7 +93,9 @@ def _stamp(src, defs):
     extra = _EXTRA["files"] if any("SMCMC_USER_LIKELIHOOD" in d for d in defs) else []
     deps = set()
     _closure(os.path.abspath(os.path.join(CSRC, src)), deps)
-    for path in sorted(deps) + extra:
+    for path in extra:   # what the user's header includes (quoted, next to it or in csrc/ include/) counts too
+        _closure(path, deps)
+    for path in sorted(deps):
         h.update(os.path.basename(path).encode())
         h.update(open(path, "rb").read())
     return h.hexdigest()
@@ -109,6 +112,7 @@ def _compile(unit):
     # are (stale objects keep their old stamp and are rebuilt by the next full build)
     only = os.environ.get("SMCMC_BUILD_ONLY")
     if only and name not in only.split(",") and os.path.exists(obj):
+        _STALE.append(name)
         return obj, False
     cmd = [HIPCC] + FLAGS + defs + ["-c", os.path.join(CSRC, src), "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
@@ -158,6 +162,13 @@ def build(jobs=None, verbose=False, user_likelihood=None, output=None, with_plai
             built[unit[2]] = (obj, did)
             if verbose and did:
                 print("built", os.path.basename(obj), flush=True)
+    if _STALE:
+        # a development shortcut, never a release build: objects of different source states may disagree about shared
+        # structs (StepParams, PanelParams, ...)
+        print("WARNING: SMCMC_BUILD_ONLY linked %d stale object(s) whose sources changed: %s\n"
+              "         run a full build before trusting this library" % (len(_STALE), ", ".join(sorted(set(_STALE)))),
+              file=sys.stderr, flush=True)
+        del _STALE[:]
     result = None
     for units, lib_path in ((plain_units if want_plain else None, LIB_PATH), (user_units or None, user_lib)):
         if not units:

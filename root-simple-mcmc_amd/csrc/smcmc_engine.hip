@@ -21,6 +21,7 @@
 #include "smcmc_panel_mfma_kernel.hip.h"
 #include "smcmc_pooled_update.hip.h"
 #include "smcmc_fold_kernel.hip.h"
+#include "smcmc_perchain_kernel.hip.h"
 #include "smcmc_proposal.hpp"
 
 using namespace smcmc;
@@ -46,7 +47,8 @@ int pick_dp(int dim, int like) {
 
 hipError_t dispatch_step(int dp, const StepParams& p, int like, bool exact, bool fullu, bool moments,
                          hipStream_t s) {
-    const bool special = p.scan_dim >= 0 || p.uniform_mask != 0 || p.proposed != nullptr;
+    // the proposed point is stored by the SPECIAL instantiation in the reference order, by every kernel in the fused order
+    const bool special = p.scan_dim >= 0 || p.uniform_mask != 0 || (p.proposed != nullptr && exact);
     switch (dp) {
 #define SMCMC_DP_CASE(n) case n: return launch_step<n>(p, like, exact, fullu, moments, special, s);
         SMCMC_FOR_EACH_DP(SMCMC_DP_CASE)
@@ -123,6 +125,11 @@ struct smcmc_engine {
     bool host_stale = false;       // the device holds newer centre / covariance / decomposition / trials than *prop
     bool device_stale = true;      // *prop was changed on the host since the device copy was written
     struct { int updateCount, nextUpdate, lastPath; double acceptanceTrials; bool decompFull; } before_update{};
+    // SMCMC_MODE_PER_CHAIN (smcmc_perchain_kernel.hip.h): every chain's own adaptive state, [k][chain] columns
+    double *d_pc_cov = nullptr, *d_pc_ut = nullptr, *d_pc_centre = nullptr, *d_pc_last = nullptr;
+    double* d_pc_tmpl = nullptr;   // what the host hands to every chain at Start / Restore / ResetProposal: cov packed, then ut
+    int* d_pc_flag = nullptr;      // chains that stopped for the host's fallback ladder in the latest launch
+    bool pc_frozen = false;        // SMCMC_P_COVARIANCE_FROZEN
     std::string error;
 };
 
@@ -296,13 +303,14 @@ int upload_like(smcmc_engine* h) {
         if ((int)h->like_params.size() != h->dim * h->dim)
             return fail(h, SMCMC_ERR_INVALID, "QUADFORM needs dim*dim likelihood parameters (the Error matrix)");
         const int D = h->dim;
-        if (h->panel_w && h->exact) {
-            // large dimensions, reference order: one lane per chain walks the D^2-term sum of TDummyLogLikelihood.H:24-28
-            // with j innermost; it reads row i of Error^T (scalar loads) and the point from a [dim][chain] image
+        if ((h->panel_w && h->exact) || h->mode == SMCMC_MODE_PER_CHAIN) {
+            // large dimensions, reference order (and the per-chain kernel at any dimension): one lane per chain walks the
+            // D^2-term sum of TDummyLogLikelihood.H:24-28 with j innermost; it reads row i of Error^T (scalar loads) and
+            // the point from a [dim][chain] image
             std::vector<double> et((size_t)D * D);
             for (int i = 0; i < D; ++i)
                 for (int j = 0; j < D; ++j) et[(size_t)i * D + j] = h->like_params[(size_t)j * D + i];
-            if (!h->d_scratch) {
+            if (h->panel_w && !h->d_scratch) {
                 HIP_TRY(h, hipMalloc(&h->d_scratch, sizeof(double) * (size_t)h->npad * D));
                 HIP_TRY(h, hipMemsetAsync(h->d_scratch, 0, sizeof(double) * (size_t)h->npad * D, h->stream));
             }
@@ -616,6 +624,202 @@ int ensure_ring(smcmc_engine* h) {
     return SMCMC_OK;
 }
 
+// ---- SMCMC_MODE_PER_CHAIN: every chain owns its adaptive state (smcmc_perchain_kernel.hip.h) --------------------
+bool per_chain(const smcmc_engine* h) { return h->mode == SMCMC_MODE_PER_CHAIN; }
+
+int pc_alloc(smcmc_engine* h) {
+    if (h->d_pc_cov) return SMCMC_OK;
+    const size_t NP = (size_t)h->npad, D = (size_t)h->dim, npk = D * (D + 1) / 2;
+    HIP_TRY(h, hipMalloc(&h->d_pc_cov, sizeof(double) * npk * NP));
+    HIP_TRY(h, hipMalloc(&h->d_pc_ut, sizeof(double) * D * D * NP));
+    HIP_TRY(h, hipMalloc(&h->d_pc_centre, sizeof(double) * D * NP));
+    HIP_TRY(h, hipMalloc(&h->d_pc_last, sizeof(double) * D * NP));
+    HIP_TRY(h, hipMalloc(&h->d_pc_tmpl, sizeof(double) * (npk + D * D + D)));
+    HIP_TRY(h, hipMalloc(&h->d_pc_flag, sizeof(int)));
+    HIP_TRY(h, hipMemset(h->d_pc_cov, 0, sizeof(double) * npk * NP));
+    HIP_TRY(h, hipMemset(h->d_pc_ut, 0, sizeof(double) * D * D * NP));
+    HIP_TRY(h, hipMemset(h->d_pc_centre, 0, sizeof(double) * D * NP));
+    HIP_TRY(h, hipMemset(h->d_pc_last, 0, sizeof(double) * D * NP));
+    HIP_TRY(h, hipMemset(h->d_pc_flag, 0, sizeof(int)));
+    if (!h->d_proposed) {   // the proposal's image: fProposed is always kept in this mode
+        HIP_TRY(h, hipMalloc(&h->d_proposed, sizeof(double) * NP * h->dp));
+        HIP_TRY(h, hipMemset(h->d_proposed, 0, sizeof(double) * NP * h->dp));
+    }
+    h->keep_proposed = true;
+    return SMCMC_OK;
+}
+
+// the engine's layout of a decomposition: kk = j (j + 1) / 2 + i holds U(i, j), i <= j; a full matrix keeps
+// U(i, j), j < i, at npk + i (i - 1) / 2 + j
+void pc_pack_decomp(const SharedProposal& P, std::vector<double>& ut) {
+    const int D = P.D, npk = D * (D + 1) / 2;
+    ut.assign((size_t)D * D, 0.0);
+    for (int j = 0; j < D; ++j)
+        for (int i = 0; i <= j; ++i) ut[(size_t)j * (j + 1) / 2 + i] = P.decomp[(size_t)i * D + j];
+    if (P.decompFull)
+        for (int i = 1; i < D; ++i)
+            for (int j = 0; j < i; ++j) ut[(size_t)npk + (size_t)i * (i - 1) / 2 + j] = P.decomp[(size_t)i * D + j];
+}
+
+void pc_deweights(const SharedProposal& P, double& acc_w, double& acc_wW, double& cov_w, double& cov_wW) {
+    acc_w = -1.0; acc_wW = 0.0; cov_w = -1.0; cov_wW = 0.0;
+    if (P.acceptanceDeweight > 0.0) {
+        acc_w = 1.0 - std::min(P.acceptanceDeweight, 1.0);
+        acc_wW = acc_w * P.acceptanceWindow;
+    }
+    if (P.covDeweight > 0.0) {
+        cov_w = 1.0 - std::min(P.covDeweight, 1.0);
+        cov_wW = cov_w * P.covWindow;
+    }
+}
+
+// Hands the template *h->prop (what InitializeState / RestoreState / ResetProposal computed once on the host) to every
+// chain.  reset: the explicit ResetProposal() of running chains; centre: RestoreState's saved centre, or null for the
+// chain's own point.
+int pc_broadcast(smcmc_engine* h, bool reset, const double* centre) {
+    const SharedProposal& P = *h->prop;
+    const int D = h->dim, npk = D * (D + 1) / 2;
+    std::vector<double> tmpl((size_t)npk + (size_t)D * D + D, 0.0), ut;
+    for (int i = 0; i < D; ++i)
+        for (int j = 0; j <= i; ++j) tmpl[(size_t)i * (i + 1) / 2 + j] = P.cov[(size_t)i * D + j];
+    pc_pack_decomp(P, ut);
+    std::copy(ut.begin(), ut.end(), tmpl.begin() + npk);
+    if (centre) std::copy(centre, centre + D, tmpl.begin() + npk + (size_t)D * D);
+    HIP_TRY(h, hipMemcpyAsync(h->d_pc_tmpl, tmpl.data(), tmpl.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));   // pageable source
+    PerChainBroadcast b;
+    std::memset(&b, 0, sizeof(b));
+    b.nchains = h->nchains; b.npad = h->npad; b.dim = D; b.reset = reset ? 1 : 0;
+    b.cov_packed = h->d_pc_tmpl; b.ut = h->d_pc_tmpl + npk;
+    b.centre = centre ? h->d_pc_tmpl + npk + (size_t)D * D : nullptr;
+    b.decomp_full = P.decompFull ? 1 : 0; b.last_path = P.lastPath; b.update_count = P.updateCount;
+    b.sigma = P.sigma; b.sigma_trace = P.sigmaTrace; b.centre_trials = P.centreTrials; b.cov_trials = P.covTrials;
+    b.acceptance = P.acceptance; b.acceptance_trials = std::min(10.0, 0.5 * P.acceptanceWindow);   // :1482 (before the de-weighting)
+    b.next_update = P.nextUpdate;
+    const double sr = std::sqrt(1.0 / D);
+    b.sigma_floor = 0.01 * sr; b.sigma_reset = sr;
+    pc_deweights(P, b.acc_w, b.acc_wW, b.cov_w, b.cov_wW);
+    b.x = h->d_x; b.last_point = h->d_pc_last; b.centre_out = h->d_pc_centre; b.cov = h->d_pc_cov; b.ut_out = h->d_pc_ut;
+    b.lane_f64 = h->d_lane_f64; b.lane_i32 = h->d_lane_i32;
+    const hipError_t e = launch_perchain_broadcast(b, h->stream);
+    if (e != hipSuccess) return fail(h, SMCMC_ERR_HIP, std::string("per-chain broadcast launch: ") + hipGetErrorString(e));
+    return SMCMC_OK;
+}
+
+// one column of a [rows][npad] array
+template <typename T>
+hipError_t pc_get_column(const T* base, size_t npad, int chain, int rows, T* out) {
+    return hipMemcpy2D(out, sizeof(T), base + chain, npad * sizeof(T), sizeof(T), (size_t)rows, hipMemcpyDeviceToHost);
+}
+template <typename T>
+hipError_t pc_put_column(T* base, size_t npad, int chain, int rows, const T* in) {
+    return hipMemcpy2D(base + chain, npad * sizeof(T), in, sizeof(T), sizeof(T), (size_t)rows, hipMemcpyHostToDevice);
+}
+
+// The chains the latest launch stopped (a Cholesky pivot failed inside their UpdateProposal, or their covariance has
+// no trace): the fallback ladder of TSimpleMCMC.H:1134-1389 on the host, chain by chain, exactly where
+// SharedProposal::update would go on; then the chain is marked to resume its step (or, for the explicit
+// UpdateProposal() call, to be simply done).
+int pc_host_ladder(smcmc_engine* h, bool explicit_update) {
+    const int D = h->dim, npk = D * (D + 1) / 2;
+    const size_t NP = (size_t)h->npad;
+    std::vector<int32_t> status(NP);
+    HIP_TRY(h, hipMemcpy(status.data(), h->d_lane_i32 + (size_t)SMCMC_LANE_UPDATE_STATUS * NP, NP * sizeof(int32_t),
+                         hipMemcpyDeviceToHost));
+    std::vector<double> lf(SMCMC_LANE_F64_COUNT_), packed(npk), ut;
+    std::vector<int32_t> li(SMCMC_LANE_I32_COUNT_);
+    for (int c = 0; c < h->nchains; ++c) {
+        if (status[c] == kPcOk || status[c] == kPcResume) continue;
+        if (status[c] == kPcInvalidTrace) return status_of(h, UpdateStatus::InvalidTrace);     // :1025-1028
+        SharedProposal T(*h->prop);                      // the settings; the state comes from the chain
+        HIP_TRY(h, pc_get_column(h->d_lane_f64, NP, c, SMCMC_LANE_F64_COUNT_, lf.data()));
+        HIP_TRY(h, pc_get_column(h->d_lane_i32, NP, c, SMCMC_LANE_I32_COUNT_, li.data()));
+        HIP_TRY(h, pc_get_column(h->d_pc_cov, NP, c, npk, packed.data()));
+        HIP_TRY(h, pc_get_column(h->d_pc_centre, NP, c, D, T.centre.data()));
+        HIP_TRY(h, pc_get_column(h->d_pc_last, NP, c, D, T.lastPoint.data()));
+        for (int i = 0; i < D; ++i)
+            for (int j = 0; j <= i; ++j) T.C(i, j) = T.C(j, i) = packed[(size_t)i * (i + 1) / 2 + j];
+        T.initialized = true;
+        T.centreTrials = lf[SMCMC_LANE_CENTER_TRIALS]; T.covTrials = lf[SMCMC_LANE_COVARIANCE_TRIALS];
+        T.sigma = lf[SMCMC_LANE_SIGMA]; T.sigmaTrace = lf[SMCMC_LANE_SIGMA_TRACE];
+        T.acceptance = lf[SMCMC_LANE_ACCEPTANCE]; T.acceptanceTrials = lf[SMCMC_LANE_ACCEPTANCE_TRIALS];
+        T.successes = li[SMCMC_LANE_SUCCESSES]; T.nextUpdate = li[SMCMC_LANE_NEXT_UPDATE];
+        T.updateCount = li[SMCMC_LANE_UPDATE_COUNT];
+        const int st = status_of(h, T.finishUpdateOnHost(1.0));
+        if (st) return st;
+        for (int i = 0; i < D; ++i)
+            for (int j = 0; j <= i; ++j) packed[(size_t)i * (i + 1) / 2 + j] = T.cov[(size_t)i * D + j];
+        pc_pack_decomp(T, ut);
+        HIP_TRY(h, pc_put_column(h->d_pc_cov, NP, c, npk, packed.data()));
+        HIP_TRY(h, pc_put_column(h->d_pc_ut, NP, c, D * D, ut.data()));
+        HIP_TRY(h, pc_put_column(h->d_pc_centre, NP, c, D, T.centre.data()));
+        lf[SMCMC_LANE_CENTER_TRIALS] = T.centreTrials; lf[SMCMC_LANE_COVARIANCE_TRIALS] = T.covTrials;
+        lf[SMCMC_LANE_SIGMA] = T.sigma; lf[SMCMC_LANE_SIGMA_TRACE] = T.sigmaTrace;
+        lf[SMCMC_LANE_ACCEPTANCE] = T.acceptance; lf[SMCMC_LANE_ACCEPTANCE_TRIALS] = T.acceptanceTrials;
+        li[SMCMC_LANE_SUCCESSES] = T.successes; li[SMCMC_LANE_NEXT_UPDATE] = T.nextUpdate;
+        li[SMCMC_LANE_UPDATE_COUNT] = T.updateCount; li[SMCMC_LANE_LAST_UPDATE_PATH] = T.lastPath;
+        li[SMCMC_LANE_DECOMP_FULL] = T.decompFull ? 1 : 0;
+        if (T.lastPath == 4) li[SMCMC_LANE_TRIALS] = 0;    // the ladder ended in ResetProposal (:1389, 1405)
+        li[SMCMC_LANE_UPDATE_STATUS] = explicit_update ? kPcOk : kPcResume;
+        HIP_TRY(h, pc_put_column(h->d_lane_f64, NP, c, SMCMC_LANE_F64_COUNT_, lf.data()));
+        HIP_TRY(h, pc_put_column(h->d_lane_i32, NP, c, SMCMC_LANE_I32_COUNT_, li.data()));
+    }
+    return SMCMC_OK;
+}
+
+PerChainParams pc_params(smcmc_engine* h, const StepParams& p) {
+    const SharedProposal& P = *h->prop;
+    PerChainParams q;
+    std::memset(&q, 0, sizeof(q));
+    q.nchains = p.nchains; q.npad = p.npad; q.dim = p.dim; q.metropolis = p.metropolis;
+    q.step0 = h->total_steps; q.target_step = h->total_steps + (uint32_t)p.nsteps;
+    q.chain_offset = p.chain_offset; q.seed = p.seed; q.like = h->d_like;
+    q.target = p.target; q.acc_window = p.acc_window; q.asig = p.asig; q.max_up = p.max_up;
+    pc_deweights(P, q.acc_w, q.acc_wW, q.cov_w, q.cov_wW);
+    q.cov_window = P.covWindow; q.cov_frozen = h->pc_frozen ? 1 : 0;
+    q.step_rms_window = p.step_rms_window;
+    q.has_forced = p.has_forced; q.forced = p.forced;
+    q.x = h->d_x; q.proposed = h->d_proposed; q.last_point = h->d_pc_last; q.centre = h->d_pc_centre;
+    q.cov = h->d_pc_cov; q.ut = h->d_pc_ut; q.lane_f64 = h->d_lane_f64; q.lane_i32 = h->d_lane_i32;
+    q.save_x = p.save_x; q.save_logl = p.save_logl; q.save_stride = p.save_stride;
+    q.flag_count = h->d_pc_flag;
+    return q;
+}
+
+// Launches until every chain has reached the target step: a chain whose decomposition failed waits for the host's
+// ladder and catches up in the next launch (its draws are keyed on its own step count).
+int pc_run(smcmc_engine* h, PerChainParams q) {
+    for (int round = 0; round < 1000; ++round) {
+        const hipError_t e = launch_perchain(q, h->likelihood, h->stream);
+        if (e != hipSuccess) return fail(h, SMCMC_ERR_HIP, std::string("per-chain kernel launch: ") + hipGetErrorString(e));
+        int flagged = 0;
+        HIP_TRY(h, hipMemcpyAsync(&flagged, h->d_pc_flag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        if (flagged == 0) return SMCMC_OK;
+        HIP_TRY(h, hipMemset(h->d_pc_flag, 0, sizeof(int)));
+        const int st = pc_host_ladder(h, q.update_only != 0);
+        if (st) return st;
+        if (q.update_only) return SMCMC_OK;
+        q.has_forced = 0;
+    }
+    return fail(h, SMCMC_ERR_RUNTIME, "per-chain update: the fallback ladder does not converge");
+}
+
+int pc_check_supported(smcmc_engine* h) {
+    if (h->panel_w || h->dim > kPcMaxDim)
+        return fail(h, SMCMC_ERR_UNSUPPORTED, "SMCMC_MODE_PER_CHAIN serves dim <= 63");
+    if (!h->exact)
+        return fail(h, SMCMC_ERR_UNSUPPORTED, "SMCMC_MODE_PER_CHAIN runs in reference-order arithmetic (SMCMC_P_EXACT_ARITHMETIC = 1)");
+    if (h->likelihood == SMCMC_LIKE_USER)
+        return fail(h, SMCMC_ERR_UNSUPPORTED, "SMCMC_MODE_PER_CHAIN serves the built-in likelihoods");
+    for (int d = 0; d < h->dim; ++d)
+        if (h->prop->ptype[d] != 0)
+            return fail(h, SMCMC_ERR_UNSUPPORTED, "SMCMC_MODE_PER_CHAIN: uniform proposals are served by the shared-proposal modes");
+    if (h->scan_dim >= 0)
+        return fail(h, SMCMC_ERR_UNSUPPORTED, "SMCMC_MODE_PER_CHAIN: the scan of a dimension is served by the shared-proposal modes");
+    return SMCMC_OK;
+}
+
 StepParams make_params(smcmc_engine* h, int nsteps, int metropolis) {
     const SharedProposal& P = *h->prop;
     StepParams p;
@@ -691,6 +895,15 @@ int launch(smcmc_engine* h, int nsteps, int metropolis, int stride, double* save
     if (save_x) {
         if (stride <= 0) return fail(h, SMCMC_ERR_INVALID, "save stride must be positive");
         p.save_x = save_x; p.save_logl = save_logl; p.save_stride = stride;
+    }
+    if (per_chain(h)) {
+        int st = pc_check_supported(h);
+        if (st) return st;
+        st = pc_run(h, pc_params(h, p));
+        if (st) return st;
+        h->total_steps += (uint32_t)nsteps;
+        h->has_forced = false;
+        return SMCMC_OK;
     }
     if (h->panel_w) {
         PanelParams q;
@@ -800,8 +1013,6 @@ int launch(smcmc_engine* h, int nsteps, int metropolis, int stride, double* save
     const bool moments = (h->mode == SMCMC_MODE_POOLED);
     const bool fullu = h->prop->decompFull;
     const bool exact = h->exact || fullu;   // the full (eigen) decomposition only exists in reference order
-    if (p.proposed != nullptr && !exact)
-        return fail(h, SMCMC_ERR_UNSUPPORTED, "the proposed point is kept in reference-order arithmetic only for dim <= 63");
     if ((p.scan_dim >= 0 || p.uniform_mask != 0) && !exact)
         return fail(h, SMCMC_ERR_UNSUPPORTED,
                     "uniform proposals and the scan of a dimension run in reference-order arithmetic only");
@@ -922,6 +1133,8 @@ int smcmc_destroy(smcmc_engine* h) {
     (void)hipFree(h->d_moments); (void)hipFree(h->d_chunks); (void)hipHostFree(h->h_moments);
     (void)hipFree(h->d_centre); (void)hipFree(h->d_cov); (void)hipFree(h->d_decomp); (void)hipFree(h->d_scal);
     (void)hipFree(h->d_ring); (void)hipFree(h->d_ring_logl);
+    (void)hipFree(h->d_pc_cov); (void)hipFree(h->d_pc_ut); (void)hipFree(h->d_pc_centre); (void)hipFree(h->d_pc_last);
+    (void)hipFree(h->d_pc_tmpl); (void)hipFree(h->d_pc_flag);
     (void)hipHostFree(h->h_scal);
     if (h->status_event) (void)hipEventDestroy(h->status_event);
     delete h->prop;
@@ -931,6 +1144,11 @@ int smcmc_destroy(smcmc_engine* h) {
 
 int smcmc_set_stream(smcmc_engine* h, void* hip_stream) {
     if (!h) return SMCMC_ERR_INVALID;
+    ON_DEVICE(h);
+    // a pooled update (and the copy of its status block) may still be queued on the old stream: resolve it and drain
+    // the stream before anything is launched on the new one
+    { int sst_ = check_pending(h); if (sst_) return sst_; }
+    if (h->d_x) HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->stream = (hipStream_t)hip_stream;
     return SMCMC_OK;
 }
@@ -944,7 +1162,11 @@ int smcmc_set_likelihood_params(smcmc_engine* h, const double* params, int count
 }
 
 int smcmc_set_mode(smcmc_engine* h, int mode) {
-    if (!h || (mode != SMCMC_MODE_FROZEN && mode != SMCMC_MODE_POOLED)) return SMCMC_ERR_INVALID;
+    if (!h || (mode != SMCMC_MODE_FROZEN && mode != SMCMC_MODE_POOLED && mode != SMCMC_MODE_PER_CHAIN)) return SMCMC_ERR_INVALID;
+    if (h->started && mode != h->mode && (mode == SMCMC_MODE_PER_CHAIN || h->mode == SMCMC_MODE_PER_CHAIN))
+        return fail(h, SMCMC_ERR_LOGIC, "SMCMC_MODE_PER_CHAIN is chosen before Start");
+    if (mode == SMCMC_MODE_PER_CHAIN && (h->panel_w || h->dim > kPcMaxDim))
+        return fail(h, SMCMC_ERR_UNSUPPORTED, "SMCMC_MODE_PER_CHAIN serves dim <= 63");
     h->mode = mode;
     h->prop->covFrozen = (mode == SMCMC_MODE_FROZEN);
     return SMCMC_OK;
@@ -1043,8 +1265,13 @@ int smcmc_set_param(smcmc_engine* h, int which, double v) {
         case SMCMC_P_NEXT_UPDATE:
             P.nextUpdate = (int)v;
             return h->started ? broadcast_lane_i32(h, SMCMC_LANE_NEXT_UPDATE, (int32_t)v) : SMCMC_OK;
-        case SMCMC_P_COVARIANCE_TRIALS: P.covTrials = v; return SMCMC_OK;
-        case SMCMC_P_CENTER_TRIALS: P.centreTrials = v; return SMCMC_OK;
+        case SMCMC_P_COVARIANCE_TRIALS:
+            P.covTrials = v;
+            return (per_chain(h) && h->started) ? broadcast_lane_f64(h, SMCMC_LANE_COVARIANCE_TRIALS, v) : SMCMC_OK;
+        case SMCMC_P_CENTER_TRIALS:
+            P.centreTrials = v;
+            return (per_chain(h) && h->started) ? broadcast_lane_f64(h, SMCMC_LANE_CENTER_TRIALS, v) : SMCMC_OK;
+        case SMCMC_P_COVARIANCE_FROZEN: h->pc_frozen = (v != 0.0); return SMCMC_OK;
         case SMCMC_P_EXACT_ARITHMETIC:
             h->exact = (v != 0.0);
             if (h->started) {                                  // the fused order keeps its own operand images
@@ -1088,6 +1315,41 @@ int smcmc_get_param(smcmc_engine* h, int which, double* out) {
         if (sst_) return sst_;
     }
     const SharedProposal& P = *h->prop;
+    if (per_chain(h) && h->started) {
+        // the members every chain keeps for itself: chain 0 answers
+        const size_t NP = (size_t)h->npad;
+        int lane_f = -1, lane_i = -1;
+        switch (which) {
+            case SMCMC_P_COVARIANCE_TRIALS: lane_f = SMCMC_LANE_COVARIANCE_TRIALS; break;
+            case SMCMC_P_CENTER_TRIALS: lane_f = SMCMC_LANE_CENTER_TRIALS; break;
+            case SMCMC_P_SIGMA_TRACE: lane_f = SMCMC_LANE_SIGMA_TRACE; break;
+            case SMCMC_P_NEXT_UPDATE: lane_i = SMCMC_LANE_NEXT_UPDATE; break;
+            case SMCMC_P_UPDATE_COUNT: lane_i = SMCMC_LANE_UPDATE_COUNT; break;
+            case SMCMC_P_LAST_UPDATE_PATH: lane_i = SMCMC_LANE_LAST_UPDATE_PATH; break;
+            default: break;
+        }
+        if (lane_f >= 0) {
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+            HIP_TRY(h, hipMemcpy(out, h->d_lane_f64 + (size_t)lane_f * NP, sizeof(double), hipMemcpyDeviceToHost));
+            return SMCMC_OK;
+        }
+        if (lane_i >= 0) {
+            int32_t v = 0;
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+            HIP_TRY(h, hipMemcpy(&v, h->d_lane_i32 + (size_t)lane_i * NP, sizeof(int32_t), hipMemcpyDeviceToHost));
+            *out = v;
+            return SMCMC_OK;
+        }
+        if (which == SMCMC_P_COVARIANCE_TRACE) {
+            std::vector<double> cov((size_t)h->dim * h->dim);
+            int st = smcmc_read_chain_proposal(h, 0, nullptr, cov.data(), nullptr);
+            if (st) return st;
+            double t = 0.0;
+            for (int i = 0; i < h->dim; ++i) t += cov[(size_t)i * h->dim + i];
+            *out = t;
+            return SMCMC_OK;
+        }
+    }
     switch (which) {
         case SMCMC_P_COVARIANCE_WINDOW: *out = P.covWindow; break;
         case SMCMC_P_COVARIANCE_DEWEIGHT: *out = P.covDeweight; break;
@@ -1118,6 +1380,7 @@ int smcmc_get_param(smcmc_engine* h, int which, double* out) {
         case SMCMC_P_KEEP_PROPOSED: *out = h->keep_proposed ? 1.0 : 0.0; break;
         case SMCMC_P_DEVICE_UPDATE: *out = h->device_update ? 1.0 : 0.0; break;
         case SMCMC_P_OVERLAP_UPDATE: *out = h->overlap_update ? 1.0 : 0.0; break;
+        case SMCMC_P_COVARIANCE_FROZEN: *out = (h->pc_frozen || h->mode == SMCMC_MODE_FROZEN) ? 1.0 : 0.0; break;
         default: return fail(h, SMCMC_ERR_INVALID, "unknown parameter");
     }
     return SMCMC_OK;
@@ -1154,7 +1417,7 @@ static int place_chains(smcmc_engine* h, const double* x0, int broadcast, std::v
         q.save_stride = 1;
         hipError_t e = launch_panel_mfma(q, h->likelihood, h->stream);
         if (e != hipSuccess) return fail(h, SMCMC_ERR_HIP, std::string("start kernel launch: ") + hipGetErrorString(e));
-    } else if (h->panel_w) {
+    } else if (h->panel_w || h->mode == SMCMC_MODE_PER_CHAIN) {
         hipError_t e;
 #ifdef SMCMC_USER_LIKELIHOOD
         if (h->likelihood == SMCMC_LIKE_USER)
@@ -1193,7 +1456,14 @@ int smcmc_start(smcmc_engine* h, const double* x0, int broadcast) {
     const int D = h->dim, N = h->nchains;
     const size_t NP = (size_t)h->npad;
     std::vector<double> x, logl;
-    int st = place_chains(h, x0, broadcast, x, logl);
+    int st = SMCMC_OK;
+    if (per_chain(h)) {
+        st = pc_check_supported(h);
+        if (st) return st;
+        st = pc_alloc(h);
+        if (st) return st;
+    }
+    st = place_chains(h, x0, broadcast, x, logl);
     if (st) return st;
     for (int c = 0; c < N; ++c)
         if (!std::isfinite(logl[c]) || logl[c] < -0.999999E+10)                      // :265-268
@@ -1226,6 +1496,11 @@ int smcmc_start(smcmc_engine* h, const double* x0, int broadcast) {
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     st = upload_shared(h);
     if (st) return st;
+    if (per_chain(h)) {
+        // InitializeState (:1679-1714) is the same computation for every chain but for the point it is centred on
+        st = pc_broadcast(h, false, nullptr);
+        if (st) return st;
+    }
     h->total_steps = 0;
     h->has_forced = false;
     h->started = true;
@@ -1284,6 +1559,7 @@ int smcmc_restore(smcmc_engine* h, const double* accepted, int broadcast, const 
         li[(size_t)SMCMC_LANE_TRIALS * NP + c] = s->trials;
         li[(size_t)SMCMC_LANE_SUCCESSES * NP + c] = s->successes;
         li[(size_t)SMCMC_LANE_NEXT_UPDATE * NP + c] = P.nextUpdate;
+        li[(size_t)SMCMC_LANE_CHAIN_STEPS * NP + c] = s->total_steps;
     }
     HIP_TRY(h, hipMemcpyAsync(h->d_lane_f64, lf.data(), lf.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->d_lane_i32, li.data(), li.size() * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
@@ -1291,7 +1567,10 @@ int smcmc_restore(smcmc_engine* h, const double* accepted, int broadcast, const 
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->total_steps = (uint32_t)s->total_steps;
     h->has_forced = false;
-    return upload_shared(h);
+    st = upload_shared(h);
+    if (st) return st;
+    if (per_chain(h)) return pc_broadcast(h, false, s->central_point);   // RestoreState for every chain (:1501-1612)
+    return SMCMC_OK;
 }
 
 int smcmc_step(smcmc_engine* h, int nsteps, int metropolis) {
@@ -1391,6 +1670,7 @@ struct RcclApi {
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     bool ok = false;
@@ -1409,6 +1689,7 @@ RcclApi& rccl_api() {
         a.GetUniqueId = (decltype(a.GetUniqueId))dlsym(a.lib, "ncclGetUniqueId");
         a.CommInitRank = (decltype(a.CommInitRank))dlsym(a.lib, "ncclCommInitRank");
         a.CommDestroy = (decltype(a.CommDestroy))dlsym(a.lib, "ncclCommDestroy");
+        a.CommCount = (decltype(a.CommCount))dlsym(a.lib, "ncclCommCount");
         a.AllReduce = (decltype(a.AllReduce))dlsym(a.lib, "ncclAllReduce");
         a.GetErrorString = (decltype(a.GetErrorString))dlsym(a.lib, "ncclGetErrorString");
         a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.AllReduce && a.GetErrorString;
@@ -1457,6 +1738,15 @@ int smcmc_comm_destroy(smcmc_engine* h) {
     return SMCMC_OK;
 }
 
+int smcmc_comm_ranks(smcmc_engine* h) {
+    if (!h) return -1;
+    if (!h->comm) return 0;
+    RcclApi& api = rccl_api();
+    int n = -1;
+    if (!api.CommCount || api.CommCount(h->comm, &n) != ncclSuccess) return -1;
+    return n;
+}
+
 // sum of the packed moment vector M over the ranks, in place, on the engine's stream
 int smcmc_allreduce_moments(smcmc_engine* h) {
     if (!h || !h->started) return SMCMC_ERR_INVALID;
@@ -1473,6 +1763,14 @@ int smcmc_update_proposal(smcmc_engine* h) {
     ON_DEVICE(h);
     { int sst_ = sync_shared_to_host(h, true); if (sst_) return sst_; }
     SharedProposal& P = *h->prop;
+    if (per_chain(h)) {
+        // every chain's own UpdateProposal() (SimpleMCMC.C:254): the step kernel's update code without a step
+        int pst = pc_check_supported(h);
+        if (pst) return pst;
+        PerChainParams q = pc_params(h, make_params(h, 0, 0));
+        q.update_only = 1;
+        return pc_run(h, q);
+    }
     int st = update_shared(h);
     if (st) return st;
     if (h->mode == SMCMC_MODE_FROZEN && P.lastPath != 4) {
@@ -1503,6 +1801,7 @@ int smcmc_reset_proposal(smcmc_engine* h) {
     P.lastPoint = x0;
     st = status_of(h, P.reset());
     if (st) return st;
+    if (per_chain(h)) return pc_broadcast(h, true, nullptr);   // the covariance template is the same for every chain; the rest per lane
     st = reset_lanes(h);
     if (st) return st;
     HIP_TRY(h, hipMemsetAsync(h->d_gacc, 0, sizeof(double) * gacc_doubles(h), h->stream));
@@ -1558,8 +1857,73 @@ int smcmc_read_lane_i32(smcmc_engine* h, int field, int32_t* out) {
     return SMCMC_OK;
 }
 
+int smcmc_read_chain(smcmc_engine* h, int chain, double* x, double* proposed, double* lanes_f64, int32_t* lanes_i32) {
+    if (!h || chain < 0 || chain >= h->nchains) return SMCMC_ERR_INVALID;
+    ON_DEVICE(h);
+    { int sst_ = check_pending(h); if (sst_) return sst_; }
+    if (proposed && (!h->keep_proposed || !h->d_proposed))
+        return fail(h, SMCMC_ERR_LOGIC, "the proposed point is not kept: set SMCMC_P_KEEP_PROPOSED first");
+    const size_t NP = (size_t)h->npad;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (x) HIP_TRY(h, pc_get_column(h->d_x, NP, chain, h->dim, x));
+    if (proposed) HIP_TRY(h, pc_get_column(h->d_proposed, NP, chain, h->dim, proposed));
+    if (lanes_f64) HIP_TRY(h, pc_get_column(h->d_lane_f64, NP, chain, SMCMC_LANE_F64_COUNT_, lanes_f64));
+    if (lanes_i32) HIP_TRY(h, pc_get_column(h->d_lane_i32, NP, chain, SMCMC_LANE_I32_COUNT_, lanes_i32));
+    return SMCMC_OK;
+}
+
+int smcmc_read_chain_proposal(smcmc_engine* h, int chain, double* centre, double* covariance, double* decomposition) {
+    if (!h || chain < 0 || chain >= h->nchains) return SMCMC_ERR_INVALID;
+    ON_DEVICE(h);
+    const int D = h->dim;
+    if (!per_chain(h) || !h->d_pc_cov) {
+        int sst_ = sync_shared_to_host(h, false);
+        if (sst_) return sst_;
+        if (centre) std::copy(h->prop->centre.begin(), h->prop->centre.end(), centre);
+        if (covariance) std::copy(h->prop->cov.begin(), h->prop->cov.end(), covariance);
+        if (decomposition) std::copy(h->prop->decomp.begin(), h->prop->decomp.end(), decomposition);
+        return SMCMC_OK;
+    }
+    const size_t NP = (size_t)h->npad;
+    const int npk = D * (D + 1) / 2;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (centre) HIP_TRY(h, pc_get_column(h->d_pc_centre, NP, chain, D, centre));
+    if (covariance) {
+        std::vector<double> packed(npk);
+        HIP_TRY(h, pc_get_column(h->d_pc_cov, NP, chain, npk, packed.data()));
+        for (int i = 0; i < D; ++i)
+            for (int j = 0; j <= i; ++j)
+                covariance[(size_t)i * D + j] = covariance[(size_t)j * D + i] = packed[(size_t)i * (i + 1) / 2 + j];
+    }
+    if (decomposition) {
+        std::vector<double> ut((size_t)D * D);
+        int32_t full = 0;
+        HIP_TRY(h, pc_get_column(h->d_pc_ut, NP, chain, D * D, ut.data()));
+        HIP_TRY(h, hipMemcpy(&full, h->d_lane_i32 + (size_t)SMCMC_LANE_DECOMP_FULL * NP + chain, sizeof(int32_t), hipMemcpyDeviceToHost));
+        std::fill(decomposition, decomposition + (size_t)D * D, 0.0);
+        for (int j = 0; j < D; ++j)
+            for (int i = 0; i <= j; ++i) decomposition[(size_t)i * D + j] = ut[(size_t)j * (j + 1) / 2 + i];
+        if (full)
+            for (int i = 1; i < D; ++i)
+                for (int j = 0; j < i; ++j) decomposition[(size_t)i * D + j] = ut[(size_t)npk + (size_t)i * (i - 1) / 2 + j];
+    }
+    return SMCMC_OK;
+}
+
+// SMCMC_MODE_PER_CHAIN: a [rows] vector handed to every chain's column
+static int pc_broadcast_rows(smcmc_engine* h, double* dst, const double* values, int rows) {
+    const size_t NP = (size_t)h->npad;
+    std::vector<double> img((size_t)rows * NP, 0.0);
+    for (int r = 0; r < rows; ++r)
+        for (int c = 0; c < h->nchains; ++c) img[(size_t)r * NP + c] = values[r];
+    HIP_TRY(h, hipMemcpyAsync(dst, img.data(), img.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SMCMC_OK;
+}
+
 int smcmc_get_center(smcmc_engine* h, double* out) {
     if (!h || !out) return SMCMC_ERR_INVALID;
+    if (per_chain(h) && h->d_pc_cov) return smcmc_read_chain_proposal(h, 0, out, nullptr, nullptr);
     ON_DEVICE(h);
     { int sst_ = sync_shared_to_host(h, false); if (sst_) return sst_; }
     std::copy(h->prop->centre.begin(), h->prop->centre.end(), out);
@@ -1571,11 +1935,13 @@ int smcmc_set_center(smcmc_engine* h, const double* in) {
     ON_DEVICE(h);
     { int sst_ = sync_shared_to_host(h, true); if (sst_) return sst_; }
     std::copy(in, in + h->dim, h->prop->centre.begin());
+    if (per_chain(h) && h->started) return pc_broadcast_rows(h, h->d_pc_centre, in, h->dim);
     return h->started ? upload_shared(h) : SMCMC_OK;
 }
 
 int smcmc_get_covariance(smcmc_engine* h, double* out) {
     if (!h || !out) return SMCMC_ERR_INVALID;
+    if (per_chain(h) && h->d_pc_cov) return smcmc_read_chain_proposal(h, 0, nullptr, out, nullptr);
     ON_DEVICE(h);
     { int sst_ = sync_shared_to_host(h, false); if (sst_) return sst_; }
     std::copy(h->prop->cov.begin(), h->prop->cov.end(), out);
@@ -1587,11 +1953,19 @@ int smcmc_set_covariance(smcmc_engine* h, const double* in) {
     ON_DEVICE(h);
     { int sst_ = sync_shared_to_host(h, true); if (sst_) return sst_; }
     std::copy(in, in + (size_t)h->dim * h->dim, h->prop->cov.begin());
+    if (per_chain(h) && h->started) {
+        const int D = h->dim;
+        std::vector<double> packed((size_t)D * (D + 1) / 2);
+        for (int i = 0; i < D; ++i)
+            for (int j = 0; j <= i; ++j) packed[(size_t)i * (i + 1) / 2 + j] = in[(size_t)i * D + j];
+        return pc_broadcast_rows(h, h->d_pc_cov, packed.data(), (int)packed.size());
+    }
     return SMCMC_OK;
 }
 
 int smcmc_get_decomposition(smcmc_engine* h, double* out) {
     if (!h || !out) return SMCMC_ERR_INVALID;
+    if (per_chain(h) && h->d_pc_cov) return smcmc_read_chain_proposal(h, 0, nullptr, nullptr, out);
     ON_DEVICE(h);
     { int sst_ = sync_shared_to_host(h, false); if (sst_) return sst_; }
     std::copy(h->prop->decomp.begin(), h->prop->decomp.end(), out);

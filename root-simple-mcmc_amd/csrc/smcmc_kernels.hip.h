@@ -59,6 +59,17 @@ __device__ __forceinline__ cptr_f64 as_const(const double* p) {
 }
 
 
+// smcmc_normal_pair (smcmc_detmath.h) with its two tables in LDS: the index differs from lane to lane, which LDS serves
+// in a few passes and a global load in up to 64 cache-line requests.  lt / at: 64 entries of two doubles each.
+__device__ __forceinline__ void normal_pair_lds(uint32_t w0, uint32_t w1, lds_cptr_f64x2 lt, lds_cptr_f64x2 at,
+                                                double* n0, double* n1) {
+#define SMCMC_LT_LDS(k, c) (lt[k][c])
+#define SMCMC_AT_LDS(k, c) (at[k][c])
+    SMCMC_NORMAL_PAIR_BODY(SMCMC_LT_LDS, SMCMC_AT_LDS)
+#undef SMCMC_LT_LDS
+#undef SMCMC_AT_LDS
+}
+
 // compile-time loop: f(std::integral_constant<int, 0>) ... f(<N-1>)
 template <int I, int N, typename F>
 __device__ __forceinline__ void static_for_impl(F& f) {
@@ -180,7 +191,7 @@ struct StepParams {
     int scan_uniform;          // the scanned dimension has a uniform proposal
     double scan_a, scan_b;     // uniform: bounds; Gaussian: centre, sigma
     double* proposed;          // optional [DP][npad]: the proposal of the launch's last step (fProposed, TSimpleMCMC.H:576);
-                               // only the SPECIAL instantiation looks at it
+                               // the SPECIAL instantiation and the fused-order kernels look at it
     int zero;                  // always 0; makes table addresses depend on the step so that the
                                // compiler does not hoist (and then spill) whole tables out of the loop
 };
@@ -338,6 +349,7 @@ __global__ void __launch_bounds__(kWave, 2) step_kernel(const StepParams p) {
     typedef ULayout<DP, FULLU> UL;
     __shared__ double xs[ROWS * kXStride];   // accepted point, x[row][lane]
     __shared__ __attribute__((aligned(16))) double us[UL::SIZE];   // decomposition, every lane reads the same word
+    __shared__ __attribute__((aligned(16))) double ntab[256];      // tables of the normal transform: log [64][2], angle [64][2]
 
     const int lane = threadIdx.x;
     const int group = blockIdx.x;
@@ -382,6 +394,12 @@ __global__ void __launch_bounds__(kWave, 2) step_kernel(const StepParams p) {
         }
     }
 
+    for (int k = lane; k < 128; k += kWave) {
+        ntab[k] = smcmc_log_table_dev[k];
+        ntab[128 + k] = smcmc_angle_table_dev[k];
+    }
+    const lds_cptr_f64x2 ltab = (lds_cptr_f64x2)ntab, atab = (lds_cptr_f64x2)(ntab + 128);
+
     constexpr bool STRIP = MOMENTS && Geo<DP>::STRIP;
     constexpr int NT16 = Geo<DP>::NT16;
     f64x4 acc[MOMENTS ? NT16 : 1];
@@ -424,8 +442,9 @@ __global__ void __launch_bounds__(kWave, 2) step_kernel(const StepParams p) {
         // QUADFORM: the proposal and the accepted point trade places -- the likelihood reads the proposal from
         // the LDS column, the registers keep the accepted point to put back on a reject
         constexpr bool SWAP = (LIKE == SMCMC_LIKE_QUADFORM);
-        if constexpr (SPECIAL) {
-            // GetProposed() (TSimpleMCMC.H:514): the proposal of the latest step, accepted or not
+        if constexpr (SPECIAL || !EXACT) {
+            // GetProposed() (TSimpleMCMC.H:514): the proposal of the latest step, accepted or not (in the reference
+            // order only the SPECIAL instantiation carries the store; the fused kernels all do)
             if (p.proposed != nullptr && s + 1 == p.nsteps && active) {
 #pragma unroll
                 for (int d = 0; d < DP; ++d) p.proposed[(size_t)d * NP + chain] = xp[d];
@@ -594,8 +613,8 @@ __global__ void __launch_bounds__(kWave, 2) step_kernel(const StepParams p) {
             smcmc_u32x4 blk = smcmc_draw_block(p.seed, gid, step, (uint32_t)b, SMCMC_STREAM_STEP);
             if ((uint32_t)b == (aw >> 2)) uword = smcmc_select_word(blk, aw & 3u);
             double n[4];
-            smcmc_normal_pair(blk.v[0], blk.v[1], &n[0], &n[1]);
-            if constexpr (4 * b + 2 < DP) smcmc_normal_pair(blk.v[2], blk.v[3], &n[2], &n[3]);
+            normal_pair_lds(blk.v[0], blk.v[1], ltab, atab, &n[0], &n[1]);
+            if constexpr (4 * b + 2 < DP) normal_pair_lds(blk.v[2], blk.v[3], ltab, atab, &n[2], &n[3]);
             else { n[2] = 0.0; n[3] = 0.0; }
             double sr[4];
 #pragma unroll

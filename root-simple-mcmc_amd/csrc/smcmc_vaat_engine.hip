@@ -327,10 +327,14 @@ int smcmc_vaat_start(smcmc_vaat* h, const double* x0, int broadcast) {          
     for (int d = 0; d < D; ++d)
         for (size_t c = (size_t)N; c < NP; ++c) x[(size_t)d * NP + c] = x[(size_t)d * NP];
     VAAT_TRY(h, hipMemcpyAsync(h->d_x, x.data(), x.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    VAAT_TRY(h, hipMemsetAsync(h->d_lane_f64, 0, sizeof(double) * NP * SMCMC_LANE_F64_COUNT_, h->stream));
+    // A second Start() (TSimpleMCMC.H:246-276) rewrites the point and the two likelihood values only: InitializeState
+    // returns at once (TProposeVAATStep.H:197), so fLastValue, fStepRMS and every per-dimension width stay as they are.
+    if (!h->initialized)
+        VAAT_TRY(h, hipMemsetAsync(h->d_lane_f64, 0, sizeof(double) * NP * SMCMC_LANE_F64_COUNT_, h->stream));
     // Start's likelihood call (TSimpleMCMC.H:258) and InitializeState's fLastValue (:207)
     VaatParams p = vaat_params(h, 0);
     p.init_only = 1;
+    p.restart = h->initialized ? 1 : 0;
     hipError_t e = vaat_dispatch(h, p);
     if (e != hipSuccess) return vfail(h, SMCMC_ERR_HIP, std::string("start kernel launch: ") + hipGetErrorString(e));
     std::vector<double> logl(NP);
@@ -373,9 +377,7 @@ int smcmc_vaat_step_save(smcmc_vaat* h, int nsteps, int stride, double* save_x_d
     h->total_steps += (uint32_t)nsteps;
     // every step pops one index; an empty queue is refilled (dim entries) before the pop
     const int D = h->dim;
-    int q = h->queue_len - nsteps % D;
-    if (q < 0) q += D;
-    h->queue_len = q;
+    h->queue_len = ((h->queue_len - nsteps) % D + D) % D;   // a full queue (D, after UpdateProposal) emptied by k D steps is 0
     return SMCMC_OK;
 }
 

@@ -32,6 +32,8 @@ struct VaatParams {
     int queue_len;             // entries left in fNextIndex when the launch starts (uniform over the chains)
     int shuffle_only;          // the explicit UpdateProposal() of SimpleVAAT.C:44: refill + shuffle, no step
     int init_only;             // Start (TSimpleMCMC.H:258): logL of the point in x, nothing else
+    int restart;               // init_only on a chain that was started before: InitializeState returns at once
+                               // (TProposeVAATStep.H:197), so fLastValue keeps what it had
     uint32_t step0;            // fTotalSteps before this launch
     uint32_t chain_offset;
     uint64_t seed;
@@ -180,7 +182,7 @@ __global__ void __launch_bounds__(kWave) vaat_step_kernel(const VaatParams p) {
     if (p.init_only) {
         const double l0 = loglike<DP, LIKE, EXACT>(x, likep, D);
         lf[SMCMC_LANE_LOGL * NP] = l0;
-        lf[SMCMC_LANE_LAST_VALUE * NP] = l0;                              // fLastValue = value (:207)
+        if (!p.restart) lf[SMCMC_LANE_LAST_VALUE * NP] = l0;              // fLastValue = value (:207)
         lf[SMCMC_LANE_LOGL_PROPOSED * NP] = l0;                           // fProposedLogLikelihood = L(start)
         return;
     }

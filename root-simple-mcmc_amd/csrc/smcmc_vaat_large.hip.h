@@ -46,7 +46,7 @@ __global__ void __launch_bounds__(kWave) vaat_large_kernel(const VaatParams p) {
     if (p.init_only) {
         const double l0 = serial_loglike<LIKE, EXACT>(p.x, chain, NP, D, p.like);
         lf[SMCMC_LANE_LOGL * NP] = l0;
-        lf[SMCMC_LANE_LAST_VALUE * NP] = l0;
+        if (!p.restart) lf[SMCMC_LANE_LAST_VALUE * NP] = l0;
         lf[SMCMC_LANE_LOGL_PROPOSED * NP] = l0;
         return;
     }

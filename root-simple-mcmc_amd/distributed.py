@@ -23,7 +23,7 @@ class HipBackend:
         self.engine = engine
         self.frozen = frozen
         self.buffer = torch.zeros(engine.moments_size, dtype=torch.float64, device="cuda")
-        self.time_steps, self.stream, self.events = time_steps, stream, []
+        self.time_steps, self.stream, self.events, self.comm_events = time_steps, stream, [], []
 
     def step(self, nsteps):
         if not self.time_steps:
@@ -53,6 +53,83 @@ class HipBackend:
         self.engine.apply_moments()
 
 
+class NativeBackend:
+    """The same window loop with the exchange inside the C library: smcmc_comm_init attaches an RCCL communicator to the
+    engine (include/smcmc.h) and the all-reduce of the moments is ncclAllReduce on the engine's stream -- the path a C++
+    caller of TSimpleMCMC_amd.H uses (InitComm / SyncPooledCovariance), no torch tensor in the data path."""
+
+    def __init__(self, engine, rank, world, unique_id, frozen=False, time_steps=False, stream=None):
+        self.engine, self.frozen = engine, frozen
+        self.time_steps, self.stream, self.events, self.comm_events = time_steps, stream, [], []
+        self.world = world
+        engine.comm_init(unique_id, rank, world)
+
+    native = True
+    step = HipBackend.step
+
+    def local_update(self):
+        e = self.engine
+        e.reduce_moments()
+        if self.time_steps:
+            import torch
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(self.stream)
+            e.allreduce_moments()
+            e1.record(self.stream)
+            self.comm_events.append((e0, e1))
+        else:
+            e.allreduce_moments()
+        e.apply_moments()
+
+
+def rank_environments(nranks, port, base_env=None, addr="127.0.0.1"):
+    """The environment of each of `nranks` local rank processes (what torch.distributed.run would set): RANK,
+    LOCAL_RANK, WORLD_SIZE, LOCAL_WORLD_SIZE, MASTER_ADDR, MASTER_PORT on top of `base_env`.  HSA_ENABLE_IPC_MODE_LEGACY=0
+    is kept / set: RCCL's intra-node transport needs dmabuf IPC on this driver."""
+    if nranks < 1:
+        raise ValueError("nranks must be positive")
+    envs = []
+    for r in range(nranks):
+        env = dict(base_env or {})
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(nranks), "LOCAL_WORLD_SIZE": str(nranks),
+                    "MASTER_ADDR": addr, "MASTER_PORT": str(port)})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        envs.append(env)
+    return envs
+
+
+def free_port(addr="127.0.0.1"):
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind((addr, 0))
+        return s.getsockname()[1]
+
+
+def launch_local_ranks(argv, nranks, visible_devices, timeout=None):
+    """Start `nranks` fresh processes of `argv` (one per GPU of this node), rank r on device r, and return
+    (exit code, rank 0's stdout).  The caller must not have touched the GPU: the children are plain child processes of
+    a GPU-free parent (never a re-exec of a process that holds a HIP context).  visible_devices: how many GPUs the
+    node has -- fewer than nranks is refused before anything starts."""
+    import os
+    import subprocess
+    if visible_devices < nranks:
+        raise RuntimeError("%d ranks asked for, %d GPU(s) visible on this node: one rank per GPU" % (nranks, visible_devices))
+    envs = rank_environments(nranks, free_port(), os.environ)
+    procs = []
+    for r, env in enumerate(envs):
+        procs.append(subprocess.Popen(argv, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate(timeout=timeout)
+    code = procs[0].returncode
+    for p in procs[1:]:
+        try:
+            p.wait(timeout=60 if code == 0 else 5)
+        except subprocess.TimeoutExpired:
+            p.kill()          # exactly the process this function started
+            p.wait()
+        code = code or p.returncode
+    return code, out.decode() if out else ""
+
+
 def shard(nchains_total, rank, world):
     """(first global chain id, number of chains) of `rank`; chains_per_rank is kept a
     multiple of 64 (one wavefront = 64 chains) except on the last rank."""
@@ -67,14 +144,22 @@ def run_windows(backend, nwindows, window, group=None):
     UpdateProposal on every rank }."""
     import torch.distributed as dist
     distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    timed = distributed and getattr(backend, "time_steps", False) and getattr(backend, "stream", None) is not None
     for _ in range(nwindows):
         backend.step(window)
         if getattr(backend, "frozen", False):
             continue
-        if not distributed and hasattr(backend, "local_update"):
-            backend.local_update()
+        if getattr(backend, "native", False) or (not distributed and hasattr(backend, "local_update")):
+            backend.local_update()        # nothing to exchange, or the exchange is the library's own (NativeBackend)
             continue
         m = backend.moments_out()
         if distributed:
+            if timed:
+                import torch
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(backend.stream)
             dist.all_reduce(m, op=dist.ReduceOp.SUM, group=group)
+            if timed:
+                e1.record(backend.stream)
+                backend.comm_events.append((e0, e1))
         backend.moments_in(m)

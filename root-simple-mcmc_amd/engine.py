@@ -10,7 +10,7 @@ import ctypes as C
 import numpy as np
 
 from . import _capi
-from ._capi import (LIKE_ASYM, LIKE_CONSTRAINED, LIKE_HORRIFIC, LIKE_ISO_GAUSS, LIKE_QUADFORM, LIKE_ROSENBROCK, LIKE_USER, MODE_FROZEN, MODE_POOLED, P,  # noqa: F401
+from ._capi import (LIKE_ASYM, LIKE_CONSTRAINED, LIKE_HORRIFIC, LIKE_ISO_GAUSS, LIKE_QUADFORM, LIKE_ROSENBROCK, LIKE_USER, MODE_FROZEN, MODE_PER_CHAIN, MODE_POOLED, P,  # noqa: F401
                     SmcmcError)
 
 _dp = C.POINTER(C.c_double)
@@ -42,6 +42,7 @@ class Engine:
             self._h = None
             raise SmcmcError(st, msg)
         self._check(self._lib.smcmc_set_mode(self._h, mode))
+        self.mode = mode
         self.set_param("EXACT_ARITHMETIC", 1.0 if exact else 0.0)
         if likelihood_params is not None:
             prm = _f64(likelihood_params).ravel()
@@ -161,9 +162,42 @@ class Engine:
         self._check(st)
         return True
 
+    def SetCovarianceFrozen(self, frozen=True):
+        """SetCovarianceFrozen (TSimpleMCMC.H:937) inside MODE_PER_CHAIN (MODE_FROZEN is the shared-decomposition form)."""
+        self.set_param("COVARIANCE_FROZEN", 1.0 if frozen else 0.0)
+
+    def chain(self, c=0):
+        """One chain's members (smcmc_read_chain): dict with accepted, proposed (when kept) and every lane by name."""
+        x, lf = np.zeros(self.dim), np.zeros(len(_capi.LANE_F64))
+        li = np.zeros(len(_capi.LANE_I32), np.int32)
+        keep = self.get_param("KEEP_PROPOSED") != 0.0
+        prop = np.zeros(self.dim) if keep else None
+        self._check(self._lib.smcmc_read_chain(self._h, int(c), _ptr(x), _ptr(prop) if keep else None, _ptr(lf),
+                                               li.ctypes.data_as(C.POINTER(C.c_int32))))
+        out = dict(accepted=x, proposed=prop)
+        out.update({k: float(lf[i]) for k, i in _capi.LANE_F64.items()})
+        out.update({k: int(li[i]) for k, i in _capi.LANE_I32.items()})
+        return out
+
+    def chain_proposal(self, c=0):
+        """(fCentralPoint, fCurrentCov, fDecomposition) of chain c (MODE_PER_CHAIN: its own; else the shared ones)."""
+        centre, cov, dec = np.zeros(self.dim), np.zeros((self.dim, self.dim)), np.zeros((self.dim, self.dim))
+        self._check(self._lib.smcmc_read_chain_proposal(self._h, int(c), _ptr(centre), _ptr(cov), _ptr(dec)))
+        return centre, cov, dec
+
     def saved_state(self, chain=0):
         """What SaveStep(true) writes for one chain (branches of TSimpleMCMC.H:208-215, 1616-1626):
-        its point and scalar state plus the shared centre and covariance."""
+        its point and scalar state plus the centre and covariance (the chain's own in MODE_PER_CHAIN, else shared)."""
+        if self.mode == MODE_PER_CHAIN:
+            ch = self.chain(chain)
+            centre, cov, _ = self.chain_proposal(chain)
+            return dict(accepted=ch["accepted"], log_likelihood=ch["logl"], total_steps=ch["chain_steps"],
+                        step_rms=ch["step_rms"], trials=ch["trials"], successes=ch["successes"],
+                        next_update=ch["next_update"], acceptance=ch["acceptance"],
+                        acceptance_trials=ch["acceptance_trials"], sigma=ch["sigma"], central_point=centre,
+                        central_point_trials=ch["center_trials"],
+                        covariance=np.array([cov[i, j] for i in range(self.dim) for j in range(i + 1)]),
+                        covariance_trials=ch["covariance_trials"])
         cov = self.covariance
         return dict(accepted=self.GetAccepted()[:, chain].copy(),
                     log_likelihood=float(self.GetAcceptedLogLikelihood()[chain]),
@@ -277,6 +311,10 @@ class Engine:
     def comm_init(self, unique_id, rank, nranks):
         buf = C.create_string_buffer(bytes(unique_id), _capi.COMM_ID_BYTES)
         self._check(self._lib.smcmc_comm_init(self._h, buf, int(rank), int(nranks)))
+
+    def comm_ranks(self):
+        """Ranks of the attached RCCL communicator as RCCL reports them (ncclCommCount); 0 without one."""
+        return self._lib.smcmc_comm_ranks(self._h)
 
     def comm_destroy(self):
         self._check(self._lib.smcmc_comm_destroy(self._h))

@@ -6,7 +6,9 @@ ships no golden vectors, so these fixtures freeze the ORACLE's outputs (parity
 unpinned, see oracle/oracle_core.h): the CPU suite checks that the oracle still
 reproduces them, the GPU suite checks the HIP path against them without the
 oracle in the loop.  Run from the repo root:  python tests/golden/make_golden.py   (everything)
-or  python tests/golden/make_golden.py --round2   (only the fixtures added in round 2 that are not there yet).
+or  python tests/golden/make_golden.py --round2 / --round3   (only the fixtures of that round that are not there yet);
+--all rewrites every fixture (needed whenever include/smcmc_detmath.h changes the draws: round 3 did, Philox4x32-7 and the
+table-driven normal transform).
 """
 import os
 import sys
@@ -156,6 +158,44 @@ def hmc_ensemble(dim, kind, nchains, schedule, params=None, fix_leapfrog=None):
     return out
 
 
+def adaptive_chains(dim, kind, nchains, x0, window=120, forced=(20, 20, 20), run=250, tail=600):
+    """The reference's own mode: every chain adapts its own covariance every step (oracle.Chain, NOT frozen) and runs
+    UpdateProposal on its own schedule -- shortened through the acceptance window and SetNextUpdate so that a few
+    hundred steps cross several updates.  The engine's SMCMC_MODE_PER_CHAIN replays it."""
+    prm = O.like_params(kind, dim)
+    out = {"dim": dim, "kind": kind, "seed": SEED, "x0": x0, "window": window, "forced": np.array(forced), "run": run,
+           "tail": tail}
+    acc, xs, centre, cov, dec, sc = [], [], [], [], [], []
+    names = ["accepted_logl", "sigma", "acceptance", "acceptance_trials", "rigidity", "step_rms", "central_trials",
+             "cov_trials", "sigma_trace", "trials", "successes", "next_update", "update_count", "total_steps"]
+    for ch in range(nchains):
+        c = O.Chain(dim, kind=kind, params=prm if prm.size else None, seed=SEED, chain_id=ch)
+        c.set_acceptance_window(window)
+        assert c.start(x0[:, ch] if x0.ndim == 2 else x0)
+        bits = []
+        for nxt in forced:
+            c.set_next_update(nxt)
+            bits.append(c.run(run)["accepted"])
+        bits.append(c.run(tail)["accepted"])
+        c.update_proposal()
+        bits.append(c.run(16)["accepted"])
+        acc.append(np.concatenate(bits)); xs.append(c.accepted); centre.append(c.center); cov.append(c.covariance)
+        dec.append(c.decomposition)
+        s = c.scalars
+        sc.append([s[k] for k in names])
+    out.update(accepted=np.array(acc), x=np.array(xs).T, centre=np.array(centre), covariance=np.array(cov),
+               decomposition=np.array(dec), scalars=np.array(sc), scalar_names=np.array(names))
+    return out
+
+
+def round3():
+    rng = np.random.default_rng(3)
+    save_new("perchain_iso_d20.npz", lambda: adaptive_chains(20, O.LIKE_ISO, 70, np.zeros(20)))
+    save_new("perchain_rosenbrock_d6.npz", lambda: adaptive_chains(6, O.LIKE_ROSENBROCK, 66, rng.uniform(0.5, 1.5, (6, 66))))
+    save_new("perchain_iso_d50.npz", lambda: adaptive_chains(50, O.LIKE_ISO, 4, np.zeros(50), window=60, forced=(40, 30), run=500,
+                                                              tail=300))
+
+
 def save_new(name, make):
     """Round-2 fixtures are written only when absent (np.savez archives are not byte-stable; the old ones stay put)."""
     path = os.path.join(HERE, name)
@@ -182,7 +222,11 @@ def main():
     if "--round2" in sys.argv:
         round2()
         return
+    if "--round3" in sys.argv:
+        round3()
+        return
     round2()
+    round3()
     np.savez(os.path.join(HERE, "frozen_iso_d5.npz"), **frozen_chains(5, O.LIKE_ISO, 4, 300, np.zeros(5)))
     rng = np.random.default_rng(1)
     np.savez(os.path.join(HERE, "frozen_rosenbrock_d6.npz"),

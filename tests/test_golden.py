@@ -286,3 +286,82 @@ def test_hip_reproduces_adaptive_hmc_golden(gpu, name):
                                       "steps_since_update", "max_scale", "min_scale", "est_trace")])
     _hmc2_check(g, q, m, -logl, e.lane("mean_epsilon"), e.lane("leapfrog"), e.lane("reversal_len"), e.lane("acceptance"),
                 e.average, e.covariance, shared)
+
+
+# ---- round 3: the reference's own mode, every chain adapting its own covariance (SMCMC_MODE_PER_CHAIN) ----
+PERCHAIN = ["perchain_iso_d20.npz", "perchain_rosenbrock_d6.npz", "perchain_iso_d50.npz"]
+
+
+def _perchain_schedule(g):
+    """(next_update or None, steps) segments of tests/golden/make_golden.py::adaptive_chains"""
+    seg = [(int(nxt), int(g["run"])) for nxt in g["forced"]]
+    return seg + [(None, int(g["tail"])), ("update", 16)]
+
+
+@pytest.mark.parametrize("name", PERCHAIN)
+def test_oracle_reproduces_perchain_golden(oracle, name):
+    g = _load(name)
+    dim, kind = int(g["dim"]), int(g["kind"])
+    names = [str(s) for s in g["scalar_names"]]
+    for ch in (0, g["accepted"].shape[0] - 1):
+        c = oracle.Chain(dim, kind=kind, seed=int(g["seed"]), chain_id=ch)
+        c.set_acceptance_window(int(g["window"]))
+        assert c.start(g["x0"][:, ch] if g["x0"].ndim == 2 else g["x0"])
+        bits = []
+        for nxt, steps in _perchain_schedule(g):
+            if nxt == "update":
+                c.update_proposal()
+            elif nxt is not None:
+                c.set_next_update(nxt)
+            bits.append(c.run(steps)["accepted"])
+        assert np.array_equal(np.concatenate(bits), g["accepted"][ch])
+        assert np.array_equal(c.accepted, g["x"][:, ch]) and np.array_equal(c.covariance, g["covariance"][ch])
+        assert np.array_equal(c.decomposition, g["decomposition"][ch]) and np.array_equal(c.center, g["centre"][ch])
+        sc = c.scalars
+        assert [sc[k] for k in names] == list(g["scalars"][ch])
+        assert sc["update_count"] >= 4                       # Start's, forced ones inside the runs, the explicit one
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", PERCHAIN)
+def test_hip_reproduces_perchain_golden(gpu, name):
+    """No oracle in the loop: the engine's per-chain mode against the committed end states and accept sequences."""
+    g = _load(name)
+    dim, kind, nch = int(g["dim"]), int(g["kind"]), g["accepted"].shape[0]
+    prm = [100.0] if kind == 2 else None
+    e = gpu.Engine(dim, nch, likelihood=kind, likelihood_params=prm, seed=int(g["seed"]), mode=gpu.MODE_PER_CHAIN)
+    e.SetAcceptanceWindow(int(g["window"]))
+    assert e.Start(g["x0"])
+    bits = []
+    for nxt, steps in _perchain_schedule(g):
+        if nxt == "update":
+            e.UpdateProposal()
+        elif nxt is not None:
+            e.SetNextUpdate(nxt)
+        # the accept bits of every step: the first segment one step per launch, the rest through the naccept counter
+        if not bits:
+            seg = []
+            for _ in range(steps):
+                e.Step(1)
+                seg.append(e.lane("last_accept").copy())
+            bits.append(np.array(seg).T)
+        else:
+            before = e.lane("naccept").copy()
+            e.Step(steps)
+            bits.append(e.lane("naccept") - before)
+    first = int(g["run"])
+    assert np.array_equal(bits[0].astype(np.uint8), g["accepted"][:, :first])
+    off = first
+    for (nxt, steps), got in zip(_perchain_schedule(g)[1:], bits[1:]):
+        assert np.array_equal(got, g["accepted"][:, off:off + steps].sum(axis=1))
+        off += steps
+    assert np.array_equal(e.GetAccepted(), g["x"])
+    names = [str(s) for s in g["scalar_names"]]
+    lane_of = {"accepted_logl": "logl", "central_trials": "center_trials", "cov_trials": "covariance_trials",
+               "total_steps": "chain_steps"}
+    for k, name_k in enumerate(names):
+        assert np.array_equal(e.lane(lane_of.get(name_k, name_k)).astype(np.float64), g["scalars"][:, k]), name_k
+    for ch in range(nch):
+        centre, cov, dec = e.chain_proposal(ch)
+        assert np.array_equal(centre, g["centre"][ch]) and np.array_equal(cov, g["covariance"][ch])
+        assert np.array_equal(dec, g["decomposition"][ch])

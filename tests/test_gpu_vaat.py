@@ -87,6 +87,50 @@ def test_vaat_without_the_explicit_update_proposal(gpu, oracle):
     _same(e, o, "no-op UpdateProposal")
 
 
+@pytest.mark.parametrize("dim", [9, 100])
+def test_vaat_launches_of_whole_queues(gpu, oracle, dim):
+    """SimpleVAAT.C's own call sequence: Start, UpdateProposal (a full queue), then launches whose step count is a
+    multiple of the dimension.  The host's copy of the queue length has to come out 0, not dim, or the next launch
+    replays the old permutation."""
+    n = 70
+    e, o = _pair(gpu, oracle, dim, n, 0)
+    rng = np.random.default_rng(dim)
+    x0 = rng.uniform(-1.0, 1.0, size=(dim, n))
+    assert e.Start(x0) and o.start(x0)
+    e.UpdateProposal(); o.update_proposal()
+    assert e.queue_length == dim
+    e.Step(2 * dim); o.step(2 * dim)
+    assert e.queue_length == 0
+    _same(e, o, "UpdateProposal; Step(2 dim)")
+    e.Step(5); o.step(5)
+    _same(e, o, "... Step(5)")
+    e2, o2 = _pair(gpu, oracle, dim, n, 0)
+    assert e2.Start(x0) and o2.start(x0)
+    for k in range(4):                                                        # Step(dim) repeated, no explicit UpdateProposal
+        e2.Step(dim); o2.step(dim)
+        assert e2.queue_length == 0
+        _same(e2, o2, f"Step(dim) number {k + 1}")
+    e2.UpdateProposal(); o2.update_proposal()                                 # empty queue: refilled now (:178)
+    assert e2.queue_length == dim
+    e2.Step(dim); o2.step(dim)
+    _same(e2, o2, "UpdateProposal on an empty queue, Step(dim)")
+
+
+def test_vaat_second_start_keeps_the_proposal_state(gpu, oracle):
+    """A second Start() moves the chain and recomputes its likelihood; InitializeState returns at once
+    (TProposeVAATStep.H:197), so fLastValue, fStepRMS, the widths and the counters stay as they were."""
+    dim, n = 8, 64
+    e, o = _pair(gpu, oracle, dim, n, 0)
+    assert e.Start(np.zeros(dim)) and o.start(np.zeros(dim))
+    e.Step(150); o.step(150)
+    last_value, rms = e.lane("last_value").copy(), e.lane("step_rms").copy()
+    assert e.Start(np.full(dim, 0.3)) and o.start(np.full(dim, 0.3))
+    assert np.array_equal(e.lane("last_value"), last_value) and np.array_equal(e.lane("step_rms"), rms)
+    _same(e, o, "second Start")
+    e.Step(60); o.step(60)
+    _same(e, o, "steps after the second Start")
+
+
 def test_vaat_proposal_settings(gpu, oracle):
     """SetUniform / SetGaussian (:101-133), the acceptance window and rigidity (:137-148), the StepRMS window."""
     dim, n = 7, 96

@@ -331,6 +331,12 @@ SMCMC_HD double smcmc_sqrt_mid(double x) {
  * instantiate it with its own loads (smcmc_kernels.hip.h); LT(k, c) / AT(k, c) read component c of entry k. */
 #include "smcmc_normal_tables.h"
 
+/* the table entries a pair needs (a kernel fetches them ahead of the arithmetic) */
+SMCMC_HD uint32_t smcmc_normal_log_index(uint32_t w0) {
+    return ((uint32_t)(smcmc_d2u(smcmc_u01(w0)) >> 32) >> 14) & 63u;
+}
+SMCMC_HD uint32_t smcmc_normal_angle_index(uint32_t w1) { return (w1 >> 24) & 63u; }
+
 #define SMCMC_NORMAL_PAIR_BODY(LT, AT)                                                                                  \
     /* radius */                                                                                                       \
     const uint64_t ub_ = smcmc_d2u(smcmc_u01(w0));                                                                      \

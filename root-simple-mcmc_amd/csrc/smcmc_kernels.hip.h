@@ -61,10 +61,18 @@ __device__ __forceinline__ cptr_f64 as_const(const double* p) {
 
 // smcmc_normal_pair (smcmc_detmath.h) with its two tables in LDS: the index differs from lane to lane, which LDS serves
 // in a few passes and a global load in up to 64 cache-line requests.  lt / at: 64 entries of two doubles each.
-__device__ __forceinline__ void normal_pair_lds(uint32_t w0, uint32_t w1, lds_cptr_f64x2 lt, lds_cptr_f64x2 at,
-                                                double* n0, double* n1) {
-#define SMCMC_LT_LDS(k, c) (lt[k][c])
-#define SMCMC_AT_LDS(k, c) (at[k][c])
+// The two entries come in ahead of the arithmetic (normal_tables_fetch): an LDS read returns in issue order, so a
+// table read issued behind the prefetch of the next U piece would wait for the whole piece.
+struct NormalTables { f64x2 le, ae; };
+__device__ __forceinline__ NormalTables normal_tables_fetch(uint32_t w0, uint32_t w1, lds_cptr_f64x2 lt, lds_cptr_f64x2 at) {
+    NormalTables t;
+    t.le = *(volatile lds_cptr_f64x2)(lt + smcmc_normal_log_index(w0));
+    t.ae = *(volatile lds_cptr_f64x2)(at + smcmc_normal_angle_index(w1));
+    return t;
+}
+__device__ __forceinline__ void normal_pair_lds(uint32_t w0, uint32_t w1, const NormalTables& t, double* n0, double* n1) {
+#define SMCMC_LT_LDS(k, c) (t.le[c])
+#define SMCMC_AT_LDS(k, c) (t.ae[c])
     SMCMC_NORMAL_PAIR_BODY(SMCMC_LT_LDS, SMCMC_AT_LDS)
 #undef SMCMC_LT_LDS
 #undef SMCMC_AT_LDS
@@ -605,16 +613,21 @@ __global__ void __launch_bounds__(kWave, 2) step_kernel(const StepParams p) {
             // otherwise issues every read of the step up front and spills hundreds of registers.
             typedef UPieces<DP, FULLU, b> PC;
             f64x2 cur[kPiece / 2], nxt[kPiece / 2];
+
+            smcmc_u32x4 blk = smcmc_draw_block(p.seed, gid, step, (uint32_t)b, SMCMC_STREAM_STEP);
+            if ((uint32_t)b == (aw >> 2)) uword = smcmc_select_word(blk, aw & 3u);
+            // LDS reads of the block, in this order (they return in issue order): the table entries of its two pairs of
+            // normals, then the first piece of U, which stays in flight under the normals' arithmetic
+            const NormalTables t0 = normal_tables_fetch(blk.v[0], blk.v[1], ltab, atab);
+            NormalTables t1 = t0;
+            if constexpr (4 * b + 2 < DP) t1 = normal_tables_fetch(blk.v[2], blk.v[3], ltab, atab);
             {
                 constexpr int i0 = PC::row(0), c0p = PC::col(0);
                 load_piece<DP, FULLU, i0, c0p>(up, cur);
             }
-
-            smcmc_u32x4 blk = smcmc_draw_block(p.seed, gid, step, (uint32_t)b, SMCMC_STREAM_STEP);
-            if ((uint32_t)b == (aw >> 2)) uword = smcmc_select_word(blk, aw & 3u);
             double n[4];
-            normal_pair_lds(blk.v[0], blk.v[1], ltab, atab, &n[0], &n[1]);
-            if constexpr (4 * b + 2 < DP) normal_pair_lds(blk.v[2], blk.v[3], ltab, atab, &n[2], &n[3]);
+            normal_pair_lds(blk.v[0], blk.v[1], t0, &n[0], &n[1]);
+            if constexpr (4 * b + 2 < DP) normal_pair_lds(blk.v[2], blk.v[3], t1, &n[2], &n[3]);
             else { n[2] = 0.0; n[3] = 0.0; }
             double sr[4];
 #pragma unroll

@@ -658,11 +658,11 @@ def test_posterior_moments_of_known_targets(gpu):
         assert 0.15 < e.lane("acceptance").mean() < 0.40      # sigma still settling toward the 0.234 target
 
 
-def test_config1_a_million_steps_bit_for_bit(gpu, oracle):
-    """BASELINE config 1 (D=5, 10^6 Step() calls of one chain, `SimpleMCMC.C` defaults) on the device next to
-    the CPU restatement: after a million steps every lane is still bit for bit the reference chain with its
-    chain id (frozen covariance: the ensemble shares no state), and the visited points have the posterior's
-    mean and covariance."""
+def test_frozen_lanes_after_a_million_steps(gpu, oracle):
+    """D=5, 10^6 Step() calls with the covariance frozen (SetCovarianceFrozen(true), TSimpleMCMC.H:937): after a million
+    steps every lane is still bit for bit the reference chain with its chain id, and every chain has settled on the
+    target acceptance.  (BASELINE config 1 itself -- the covariance adapting, as SimpleMCMC.C runs it -- is
+    tests/test_gpu_perchain.py::test_config1_a_million_adaptive_steps.)"""
     dim, steps = 5, 1000000
     e = gpu.Engine(dim, 64, mode=gpu.MODE_FROZEN)
     assert e.Start(np.zeros(dim))

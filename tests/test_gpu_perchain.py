@@ -86,10 +86,10 @@ def test_every_lane_is_the_reference_chain(gpu, oracle, kind, dim):
     _same(e, chains, "first step")
     updates0 = e.lane("update_count").copy()
     for k in range(4):
-        _both(e, chains, "SetNextUpdate", "set_next_update", 25)   # every chain updates on its 25th accepted step from here
-        _step(e, chains, 300 if kind != 5 else 600)
+        _both(e, chains, "SetNextUpdate", "set_next_update", 12)   # every chain updates on its 12th accepted step from here
+        _step(e, chains, 300 if kind not in (2, 5) else 600)
         _same(e, chains, f"forced schedule {k}")
-    assert np.all(e.lane("update_count") >= updates0 + 2), "the launches must cross UpdateProposal events"
+    assert np.median(e.lane("update_count") - updates0) >= 3, "the launches must cross UpdateProposal events"
     _step(e, chains, 1500)
     _same(e, chains, "free running")
     _both(e, chains, "UpdateProposal", "update_proposal")
@@ -108,11 +108,11 @@ def test_headline_dimension_through_two_updates(gpu, oracle):
     _both(e, chains, "SetNextUpdate", "set_next_update", 40)
     _step(e, chains, 700)
     _same(e, chains, "first update")
-    assert np.all(e.lane("update_count") >= 3)                   # Start's, the forced one (and possibly the next)
+    assert np.all(e.lane("update_count") >= 2)                   # Start's and the forced one
     _both(e, chains, "SetNextUpdate", "set_next_update", 30)
     _step(e, chains, 500)
     _same(e, chains, "second update")
-    assert np.all(e.lane("update_count") >= 4)
+    assert np.all(e.lane("update_count") >= 3)
     assert np.all(e.lane("decomp_full") == 0) and np.all(e.lane("last_update_path") == 0)
 
 
@@ -204,18 +204,22 @@ def test_the_fallback_ladder_inside_a_launch(gpu, oracle):
     the host runs the ladder of TSimpleMCMC.H:1134-1389 for it (here: conditioning, rung 1) and the chain catches up;
     the other chains of the wavefront never notice."""
     dim, n = 6, 64
-    e, chains = _make(gpu, oracle, dim, n, 0, which=(0, 1, 2, 33, 63))
+    e, chains = _make(gpu, oracle, dim, n, 0)
     _step(e, chains, 50)
     bad = np.eye(dim)
     bad[0, 1] = bad[1, 0] = 1.0 + 1e-3                           # correlation > 1: no Cholesky factor
     e.SetCovariance(bad)
     for ch in chains.values():
         ch.set_covariance(bad)
-    _both(e, chains, "SetCovarianceTrials", "set_covariance_trials", 1e6)   # the running average barely moves it
+    _both(e, chains, "SetCovarianceWindow", "set_covariance_window", 10 ** 6)   # the running average barely moves it
+    _both(e, chains, "SetCovarianceTrials", "set_covariance_trials", 1e6)
     _both(e, chains, "SetNextUpdate", "set_next_update", 3)
-    _step(e, chains, 40)
-    assert np.all(e.lane("last_update_path") >= 1), "the ladder must have run"
+    _step(e, chains, 60)
+    paths = e.lane("last_update_path")
+    assert np.all(paths >= 1), "the ladder must have run in every chain"
     _same(e, chains, "after the ladder")
+    if np.any(paths == 2):                                       # the eigen rung leaves a full decomposition (:1252-1321)
+        assert np.array_equal(e.lane("decomp_full") == 1, paths == 2)
     _step(e, chains, 200)
     _same(e, chains, "and on")
 
@@ -252,3 +256,21 @@ def test_what_the_mode_refuses(gpu):
     e = gpu.Engine(8, 64, mode=gpu.MODE_PER_CHAIN, exact=False)
     with pytest.raises(gpu.SmcmcError):
         e.Start(np.zeros(8))
+
+
+def test_config1_a_million_adaptive_steps(gpu, oracle):
+    """BASELINE config 1: D = 5, 10^6 Step() calls of a chain with SimpleMCMC.C's defaults -- the covariance adapting
+    every step, UpdateProposal on the chain's own schedule (~230 of them) -- on the device next to the CPU restatement:
+    after a million steps the lanes are still bit for bit the reference chains of their chain ids, and what the chains
+    estimate (fCentralPoint, fCurrentCov: running averages over the covariance window of 245 steps) is the posterior's
+    mean 0 and covariance I, averaged over the 64 chains."""
+    dim, n, steps = 5, 64, 1000000
+    e, chains = _make(gpu, oracle, dim, n, 0, which=(0, 63))
+    _step(e, chains, steps)
+    _same(e, chains, "10^6 steps")
+    assert np.all(e.lane("update_count") > 100)
+    assert np.all(np.abs(e.lane("naccept") / steps - 0.234) < 0.03)
+    centre = np.array([e.chain_proposal(c)[0] for c in range(n)])
+    cov = np.array([e.chain_proposal(c)[1] for c in range(n)])
+    assert np.max(np.abs(centre.mean(axis=0))) < 0.2            # 64 windows of ~10 independent points each
+    assert np.max(np.abs(cov.mean(axis=0) - np.eye(dim))) < 0.25

@@ -154,18 +154,79 @@ def extra_metropolis(pkg, torch, stream, name, dim, chains, like, like_id, prm, 
     return out
 
 
-def extra_hmc(pkg, torch, stream, dim, chains, leapfrog, exact, steps, tuned):
+def extra_perchain(pkg, torch, stream, dim, chains, steps, launches):
+    """SMCMC_MODE_PER_CHAIN: every chain adapts its own covariance every step and decomposes it on its own schedule --
+    the reference's own mode, the one configuration whose HBM traffic per chain-step is O(D^2): the chain's packed
+    decomposition is read, its packed covariance read and written (8 * 3 * D (D + 1) / 2 bytes) on top of the O(D) state."""
+    eng = pkg.Engine(dim, chains, seed=20240607, mode=pkg.MODE_PER_CHAIN, stream=stream.cuda_stream)
+    assert eng.Start(np.zeros(dim))
+    eng.Step(8)
+    torch.cuda.synchronize()
+    evs = []
+    t0 = time.perf_counter()
+    for _ in range(launches):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream); eng.Step(steps); e1.record(stream)
+        evs.append((e0, e1))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    kms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    rate = chains * steps * launches / dt
+    nbytes = 8 * 3 * dim * (dim + 1) // 2 + 8 * 7 * dim + 16
+    out = {"workload": "TDummyLogLikelihood README form D=%d, %d chains, TProposeAdaptiveStep per chain (own covariance "
+                       "every step, own UpdateProposal schedule)" % (dim, chains),
+           "chain_steps_per_s": rate, "kernel_chain_steps_per_s": chains * steps / (kms * 1e-3),
+           "us_per_ensemble_step": kms * 1e3 / steps, "steps_per_launch": steps, "launches": launches,
+           "algorithmic_bytes_per_chain_step": nbytes, "hbm_GBps": chains * steps / (kms * 1e-3) * nbytes / 1e9,
+           "hbm_frac": chains * steps / (kms * 1e-3) * nbytes / 1e9 / HBM_PEAK_GBPS,
+           "adaptive_state_MB": chains * 8 * (dim * (dim + 1) // 2 + dim * dim + 2 * dim) / 1e6,
+           "accept_rate": float(eng.lane("naccept").sum() / (eng.get_param("TOTAL_STEPS") * chains))}
+    eng.close()
+    return out
+
+
+def hmc_ess_per_trajectory(h, nsteps=48):
+    """Effective samples per trajectory of the running ensemble (outside any timed region): nsteps more trajectories,
+    the positions read back after each, the lag autocorrelation of every 16th coordinate pooled over the chains
+    (definition of MakeAutocorrelation.C:127-148), Geyer's initial positive sequence, the worst coordinate."""
+    trace = []
+    for _ in range(nsteps):
+        h.Step(1)
+        q, _, _ = h.state()
+        trace.append(q[::16].copy())
+    x = np.array(trace)                                    # [step][coordinate][chain]
+    x = x - x.mean(axis=(0, 2), keepdims=True)
+    var = (x * x).mean(axis=(0, 2))
+    tau = np.ones(x.shape[1])
+    for d in range(x.shape[1]):
+        k = 1
+        while k + 1 < nsteps // 2:
+            pair = ((x[k:, d] * x[:-k, d]).mean() + (x[k + 1:, d] * x[:-k - 1, d]).mean()) / var[d]
+            if pair < 0:
+                break
+            tau[d] += 2.0 * pair
+            k += 2
+    return 1.0 / float(tau.max())
+
+
+def extra_hmc(pkg, torch, stream, dim, chains, leapfrog, exact, steps, tuned, burn=2, eps0=None, ess=False):
     """Config 5: TSimpleHMC, header-form TDummyLogLikelihood with its analytic gradient, start at 1 (SimpleHMC.C:45),
-    SetLeapFrog(20).  tuned: the step length is left to the chain (reference default: the covariance fold and the pooled
-    UpdateErrorMatrix run every step, inside the timed region); otherwise SetMeanEpsilon(<0) fixes it."""
+    SetLeapFrog(20).  tuned: the step length is left to the chain (the covariance fold and the pooled UpdateErrorMatrix run
+    every step, inside the timed region) -- from the reference's start value 0.05 (TSimpleHMC.H:229: 25 times the
+    stability limit of this target, every trajectory is rejected and the step length never moves), or, with eps0, from
+    SetMeanEpsilon(eps0 > 0), a start the target can take; otherwise SetMeanEpsilon(< 0) fixes it.  `burn` untimed
+    steps first; accept_rate is the acceptance inside the timed region."""
     h = pkg.HmcEngine(dim, chains, likelihood=pkg.LIKE_QUADFORM, likelihood_params=tdummy_error(dim), seed=20240607,
                       exact=exact, stream=stream.cuda_stream)
     h.Start(np.ones(dim))
     if not tuned:
         h.SetMeanEpsilon(-0.0005)
+    elif eps0 is not None:
+        h.SetMeanEpsilon(eps0)
     h.SetLeapFrog(leapfrog)
-    h.Step(2)
+    h.Step(burn)
     torch.cuda.synchronize()
+    acc0, tr0 = h.lane("naccept").astype(np.float64).sum(), h.lane("trials").astype(np.float64).sum()
     gc.collect(); gc.disable()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
@@ -177,14 +238,25 @@ def extra_hmc(pkg, torch, stream, dim, chains, leapfrog, exact, steps, tuned):
     gc.enable()
     rate = chains * steps / dt
     flops = (leapfrog + 1) * 2 * dim * dim + 3 * dim * dim + dim * dim
+    acc1, tr1 = h.lane("naccept").astype(np.float64).sum(), h.lane("trials").astype(np.float64).sum()
+    eps = h.lane("mean_epsilon")
     out = {"workload": "TSimpleHMC header-form TDummy D=%d, %d chains x %d leapfrog steps, %s step length" %
-                       (dim, chains, leapfrog, "self-tuned" if tuned else "fixed"),
+                       (dim, chains, leapfrog, ("self-tuned from SetMeanEpsilon(%g)" % eps0 if eps0 is not None else
+                                                "self-tuned from the reference's start value") if tuned else "fixed"),
            "trajectories_per_s": rate, "ms_per_step": dt / steps * 1e3, "device_ms_per_step": e0.elapsed_time(e1) / steps,
-           "steps": steps, "arithmetic": "reference-order" if exact else "fused (matrix pipe)",
+           "steps": steps, "burn_in_steps": burn, "arithmetic": "reference-order" if exact else "fused (matrix pipe)",
            "fp64_TFLOPs": rate * flops / 1e12, "fp64_frac": rate * flops / 1e12 / FP64_PEAK_TFLOPS,
            "hbm_model_frac": rate * (32 * dim + 16) / 1e9 / HBM_PEAK_GBPS,
-           "accept_rate": float(h.lane("naccept").mean() / h.lane("trials").mean()),
-           "mean_epsilon_chain0": h.GetMeanEpsilon(), "covariance_updates": h.tuning["updates"]}
+           "accept_rate": float((acc1 - acc0) / max(tr1 - tr0, 1.0)),
+           "mean_epsilon_chain0": h.GetMeanEpsilon(), "mean_abs_epsilon": float(np.abs(eps).mean()),
+           "covariance_updates": h.tuning["updates"]}
+    if ess:
+        try:
+            per = hmc_ess_per_trajectory(h)
+            out["ess_per_trajectory"] = per
+            out["ess_per_s"] = per * rate
+        except Exception as exc:
+            out["ess_error"] = repr(exc)
     h.close()
     return out
 
@@ -360,29 +432,35 @@ def main():
         try:
             extra["c2_header_tdummy"] = extra_metropolis(
                 pkg, torch, stream, "TDummyLogLikelihood header form (quadratic form) D=50, 65 536 chains, pooled", 50,
-                CHAINS_PER_GPU, "quadform", pkg.LIKE_QUADFORM, tdummy_error(50), np.zeros(50), True, 10)
+                CHAINS_PER_GPU, "quadform", pkg.LIKE_QUADFORM, tdummy_error(50), np.zeros(50), True, 20)
             x3 = rng.uniform(0.5, 1.5, (200, 16384))                  # SimpleMCMC.C:147
             for exact in (True, False):
                 extra["c3_rosenbrock_d200_16384_pooled" + ("" if exact else "_fused")] = extra_metropolis(
                     pkg, torch, stream, "THardLogLikelihood (Rosenbrock) D=200, 16 384 chains, pooled", 200, 16384,
-                    "rosenbrock", pkg.LIKE_ROSENBROCK, [100.0], x3, exact, 3)
+                    "rosenbrock", pkg.LIKE_ROSENBROCK, [100.0], x3, exact, 10)
                 extra["c4_share_d500_32768_pooled" + ("" if exact else "_fused")] = extra_metropolis(
                     pkg, torch, stream, "TDummyLogLikelihood README form D=500, 32 768 chains (one GPU's share of config 4), "
-                    "pooled, sync every 256 steps", 500, 32768, "iso", pkg.LIKE_ISO_GAUSS, None, np.zeros(500), exact, 2)
+                    "pooled, sync every 256 steps", 500, 32768, "iso", pkg.LIKE_ISO_GAUSS, None, np.zeros(500), exact, 5)
                 extra["c4_share_d500_32768_pooled_stride16" + ("" if exact else "_fused")] = extra_metropolis(
                     pkg, torch, stream, "config 4 share as above with the covariance fed every 16th step (SMCMC_P_MOMENT_STRIDE: "
                     "a thinned running covariance, not the reference's every-step update)", 500, 32768, "iso",
-                    pkg.LIKE_ISO_GAUSS, None, np.zeros(500), exact, 2, stride=16)
+                    pkg.LIKE_ISO_GAUSS, None, np.zeros(500), exact, 5, stride=16)
             extra["c4_share_d500_32768_pooled_header_tdummy"] = extra_metropolis(
                 pkg, torch, stream, "TDummyLogLikelihood header form D=500, 32 768 chains, pooled (the likelihood config 4 "
                 "names, in the reference's order: one serial D^2-term sum per chain)", 500, 32768, "quadform",
                 pkg.LIKE_QUADFORM, tdummy_error(500), np.zeros(500), True, 1)
             extra["c4_share_d500_32768_pooled_header_tdummy_fused"] = extra_metropolis(
                 pkg, torch, stream, "TDummyLogLikelihood header form D=500, 32 768 chains, pooled", 500, 32768, "quadform",
-                pkg.LIKE_QUADFORM, tdummy_error(500), np.zeros(500), False, 2)
+                pkg.LIKE_QUADFORM, tdummy_error(500), np.zeros(500), False, 5)
+            extra["perchain_d50_65536"] = extra_perchain(pkg, torch, stream, 50, 65536, 32, 3)
+            extra["perchain_d50_4096"] = extra_perchain(pkg, torch, stream, 50, 4096, 32, 3)
             extra["c5_hmc_d500_8192_L20"] = extra_hmc(pkg, torch, stream, 500, 8192, 20, True, 3, True)
             extra["c5_hmc_d500_8192_L20_fused"] = extra_hmc(pkg, torch, stream, 500, 8192, 20, False, 10, True)
-            extra["c5_hmc_d500_8192_L20_fixed_step_fused"] = extra_hmc(pkg, torch, stream, 500, 8192, 20, False, 20, False)
+            # the sampler rows: a burn-in in which the chains accept, then 200 trajectories timed
+            extra["c5_hmc_d500_8192_L20_tuned_sampler_fused"] = extra_hmc(pkg, torch, stream, 500, 8192, 20, False, 200, True,
+                                                                          burn=300, eps0=0.0005, ess=True)
+            extra["c5_hmc_d500_8192_L20_fixed_step_fused"] = extra_hmc(pkg, torch, stream, 500, 8192, 20, False, 200, False,
+                                                                       burn=100, ess=True)
         except Exception as exc:   # never a reason to lose the headline
             extra["error"] = repr(exc)
         out["extra"] = extra

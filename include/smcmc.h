@@ -110,6 +110,9 @@ typedef enum {
                                          * window late.  0 (default): parity mode */
     SMCMC_P_COVARIANCE_FROZEN = 23,     /* Set/GetCovarianceFrozen :937-938 inside SMCMC_MODE_PER_CHAIN: the covariance loop is
                                          * skipped, the centre still runs (SMCMC_MODE_FROZEN is the shared-decomposition form) */
+    SMCMC_P_SPLIT_FOLD = 24,            /* 1 (default): dim <= 63, POOLED: the moment fold runs in a second wavefront of every
+                                         * chain group's workgroup (two wavefronts per SIMD at 65 536 chains); 0: one wavefront
+                                         * does both.  The same matrix instructions in the same order: identical results. */
     SMCMC_P_COUNT_
 } smcmc_param;
 
@@ -321,6 +324,17 @@ int smcmc_hmc_get_gradient_type(const smcmc_hmc* h);
 int smcmc_hmc_set_track_covariance(smcmc_hmc* h, int on);
 int smcmc_hmc_moment_group(const smcmc_hmc* h);
 int smcmc_hmc_sync(smcmc_hmc* h);                                        /* the pooled update now (end of a run) */
+/* The same in pieces, so that an ensemble sharded over engines / ranks pools its covariance as the Metropolis engine's does:
+ * reduce (the moment groups of the steps since the last update summed into the packed device vector M[(dim+1)(dim+2)/2]:
+ * sum x x^T by rows j <= i, then sum x and the number of points), export / import (copy M to / from a caller-owned DEVICE
+ * buffer: the caller adds the ranks' vectors, e.g. one RCCL all-reduce), apply (UpdateCovariance fed with the batch, then
+ * UpdateErrorMatrix, the same on every rank).  Set the sync interval beyond the steps of a window and call these at its
+ * end; smcmc_hmc_sync = reduce + apply. */
+int smcmc_hmc_moments_size(const smcmc_hmc* h);
+int smcmc_hmc_reduce_moments(smcmc_hmc* h);
+int smcmc_hmc_export_moments(smcmc_hmc* h, double* dst_device);
+int smcmc_hmc_import_moments(smcmc_hmc* h, const double* src_device);
+int smcmc_hmc_apply_moments(smcmc_hmc* h);
 /* out[10]: fCurrentCovarianceTrace, fEstimatedOrbitLength, updates that went through, fCovarianceTrials,
  * fAveragePointTrials, fStepsRemaining, fStepsSinceUpdate, max scale, min scale, fEstimatedCovarianceTrace */
 int smcmc_hmc_get_tuning(smcmc_hmc* h, double* out);

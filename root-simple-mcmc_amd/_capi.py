@@ -20,7 +20,7 @@ PARAMS = ["COVARIANCE_WINDOW", "COVARIANCE_DEWEIGHT", "ACCEPTANCE_WINDOW", "ACCE
           "ACCEPTANCE_RIGIDITY", "TARGET_ACCEPTANCE", "SIGMA", "MAXIMUM_CORRELATION", "STEP_RMS_WINDOW",
           "NEXT_UPDATE", "COVARIANCE_TRIALS", "CENTER_TRIALS", "COVARIANCE_TRACE", "TOTAL_STEPS",
           "SIGMA_TRACE", "UPDATE_COUNT", "LAST_UPDATE_PATH", "EXACT_ARITHMETIC", "MOMENT_STRIDE", "MOMENT_GROUP", "KEEP_PROPOSED",
-          "DEVICE_UPDATE", "OVERLAP_UPDATE", "COVARIANCE_FROZEN"]
+          "DEVICE_UPDATE", "OVERLAP_UPDATE", "COVARIANCE_FROZEN", "SPLIT_FOLD"]
 P = {name: i for i, name in enumerate(PARAMS)}
 LANE_F64 = {name: i for i, name in enumerate(
     ["logl", "sigma", "acceptance", "acceptance_trials", "rigidity", "last_value", "last_x0", "step_rms",
@@ -121,6 +121,11 @@ SIGNATURES = {
     "smcmc_hmc_get_gradient_type": (C.c_int, [_H]),
     "smcmc_hmc_moment_group": (C.c_int, [_H]),
     "smcmc_hmc_sync": (C.c_int, [_H]),
+    "smcmc_hmc_moments_size": (C.c_int, [_H]),
+    "smcmc_hmc_reduce_moments": (C.c_int, [_H]),
+    "smcmc_hmc_export_moments": (C.c_int, [_H, C.c_void_p]),
+    "smcmc_hmc_import_moments": (C.c_int, [_H, C.c_void_p]),
+    "smcmc_hmc_apply_moments": (C.c_int, [_H]),
     "smcmc_hmc_get_tuning": (C.c_int, [_H, _dp]),
     "smcmc_hmc_get_average_point": (C.c_int, [_H, _dp]),
     "smcmc_hmc_get_covariance": (C.c_int, [_H, _dp]),

@@ -45,6 +45,7 @@ struct smcmc_hmc {
     HmcShared* shared = nullptr;
     bool track_cov = false;        // keep the running covariance even with a fixed step and count
     int sync_every = 1, steps_in_window = 0;
+    int steps_reduced = 0;   // steps whose moments are in d_moments, waiting for hmc_apply (between reduce and apply)
     int fold_nslices = 0, slice_chains = 0;
     double *d_p0 = nullptr, *d_qprev = nullptr, *d_gacc = nullptr, *d_moments = nullptr, *d_zero = nullptr;
     double* h_moments = nullptr;   // pinned: the packed moments come back every sync
@@ -313,14 +314,33 @@ int hmc_pull(smcmc_hmc* h) {
     return SMCMC_OK;
 }
 
-// The pooled UpdateCovariance + UpdateErrorMatrix (TSimpleHMC.H:337-341) for the steps since the last one
-int hmc_sync(smcmc_hmc* h) {
-    const int steps = h->steps_in_window;
+// The moment groups of the steps since the last update summed (in group order) into the packed vector M, which is what
+// crosses ranks when the ensemble is sharded (smcmc_hmc_export_moments / import).
+int hmc_reduce(smcmc_hmc* h) {
+    h->steps_reduced += h->steps_in_window;
     h->steps_in_window = 0;
-    if (steps == 0) return SMCMC_OK;
     hipError_t e = launch_fold_reduce(h->d_gacc, h->dim, h->fold_nslices, h->d_moments, h->stream);
     if (e != hipSuccess) return hfail(h, SMCMC_ERR_HIP, std::string("fold reduce launch: ") + hipGetErrorString(e));
     HMC_TRY(h, hipMemsetAsync(h->d_gacc, 0, sizeof(double) * hmc_gacc_doubles(h), h->stream));
+    return SMCMC_OK;
+}
+
+int hmc_apply(smcmc_hmc* h);
+
+// The pooled UpdateCovariance + UpdateErrorMatrix (TSimpleHMC.H:337-341) for the steps since the last one
+int hmc_sync(smcmc_hmc* h) {
+    if (h->steps_in_window == 0) return SMCMC_OK;
+    int st = hmc_reduce(h);
+    if (st) return st;
+    return hmc_apply(h);
+}
+
+// the running averages absorb the batch M and UpdateErrorMatrix decides (every rank of a sharded ensemble the same)
+int hmc_apply(smcmc_hmc* h) {
+    const int steps = h->steps_reduced;
+    h->steps_reduced = 0;
+    if (steps == 0) return SMCMC_OK;
+    hipError_t e;
     // the running averages absorb the batch on the device; four scalars come back for UpdateErrorMatrix's decision
     HmcShared& S = *h->shared;
     if (!h->shared_on_device) {
@@ -677,6 +697,39 @@ int smcmc_hmc_sync(smcmc_hmc* h) {
     HMC_ON_DEVICE(h);
     if (!h->d_gacc) return SMCMC_OK;
     return hmc_sync(h);
+}
+
+// The same in pieces, for an ensemble sharded over engines / ranks: reduce, export, (sum over ranks), import, apply.
+int smcmc_hmc_moments_size(const smcmc_hmc* h) { return h ? (int)(((size_t)h->dim + 1) * ((size_t)h->dim + 2) / 2) : 0; }
+
+int smcmc_hmc_reduce_moments(smcmc_hmc* h) {
+    if (!h || !h->started) return SMCMC_ERR_INVALID;
+    HMC_ON_DEVICE(h);
+    int st = hmc_tracking_buffers(h);
+    if (st) return st;
+    return hmc_reduce(h);
+}
+
+int smcmc_hmc_export_moments(smcmc_hmc* h, double* dst_device) {
+    if (!h || !dst_device || !h->d_moments) return SMCMC_ERR_INVALID;
+    HMC_ON_DEVICE(h);
+    HMC_TRY(h, hipMemcpyAsync(dst_device, h->d_moments, sizeof(double) * (size_t)smcmc_hmc_moments_size(h), hipMemcpyDeviceToDevice,
+                              h->stream));
+    return SMCMC_OK;
+}
+
+int smcmc_hmc_import_moments(smcmc_hmc* h, const double* src_device) {
+    if (!h || !src_device || !h->d_moments) return SMCMC_ERR_INVALID;
+    HMC_ON_DEVICE(h);
+    HMC_TRY(h, hipMemcpyAsync(h->d_moments, src_device, sizeof(double) * (size_t)smcmc_hmc_moments_size(h), hipMemcpyDeviceToDevice,
+                              h->stream));
+    return SMCMC_OK;
+}
+
+int smcmc_hmc_apply_moments(smcmc_hmc* h) {
+    if (!h || !h->started || !h->d_moments) return SMCMC_ERR_INVALID;
+    HMC_ON_DEVICE(h);
+    return hmc_apply(h);
 }
 
 int smcmc_hmc_read_state(smcmc_hmc* h, double* q, double* momentum, double* logl) {

@@ -200,6 +200,7 @@ struct StepParams {
     double scan_a, scan_b;     // uniform: bounds; Gaussian: centre, sigma
     double* proposed;          // optional [DP][npad]: the proposal of the launch's last step (fProposed, TSimpleMCMC.H:576);
                                // the SPECIAL instantiation and the fused-order kernels look at it
+    int split;                 // pooled, no special proposal, no forced step: the SPLIT instantiation (a second wavefront folds)
     int zero;                  // always 0; makes table addresses depend on the step so that the
                                // compiler does not hoist (and then spill) whole tables out of the loop
 };
@@ -348,8 +349,16 @@ __device__ __forceinline__ double loglike_quadform_lds(const double* xq, cptr_f6
     return logl;
 }
 
-template <int DP, int LIKE, bool EXACT, bool FULLU, bool MOMENTS, bool SPECIAL>
-__global__ void __launch_bounds__(kWave, 2) step_kernel(const StepParams p) {
+// SPLIT = the pooled moments are folded by a SECOND wavefront of the workgroup (a workgroup is then 128 threads for
+// the same 64 chains): the step wavefront runs the MOMENTS = false code, the fold wavefront reads the accepted points
+// from the shared LDS image and issues the matrix instructions, two barriers per step between them (before and after
+// the accept copy).  A lone wavefront per SIMD leaves a third of its cycles idle (LDS waits, dependent chains); with
+// 65 536 chains there is exactly one step wavefront per SIMD, and the fold wavefront of another workgroup fills those
+// cycles.  Same matrix instructions in the same order on the same accumulators: the moments do not change by a bit.
+template <int DP, int LIKE, bool EXACT, bool FULLU, bool MOMENTS, bool SPECIAL, bool SPLIT = false>
+__global__ void __launch_bounds__(SPLIT ? 2 * kWave : kWave, 2) step_kernel(const StepParams p) {
+    static_assert(!SPLIT || (MOMENTS && !SPECIAL), "the split form is the pooled kernel without the special proposals");
+    constexpr bool FOLD = MOMENTS && !SPLIT;   // this wavefront folds the moments itself
     constexpr int T = Geo<DP>::T;
     constexpr int NT = Geo<DP>::NT;
     constexpr int NB = Geo<DP>::NB;
@@ -359,9 +368,22 @@ __global__ void __launch_bounds__(kWave, 2) step_kernel(const StepParams p) {
     __shared__ __attribute__((aligned(16))) double us[UL::SIZE];   // decomposition, every lane reads the same word
     __shared__ __attribute__((aligned(16))) double ntab[256];      // tables of the normal transform: log [64][2], angle [64][2]
 
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & (kWave - 1);
     const int group = blockIdx.x;
     const int chain = group * kWave + lane;
+    // SPLIT: which of the two wavefronts steps and which folds.  Two workgroups share a SIMD pair; the choice below
+    // puts one wavefront of each kind on a SIMD when the hardware places them the usual way (both wavefronts of a
+    // workgroup in the same slot of neighbouring SIMDs); any other placement only costs balance.
+    bool stepper = true;
+    if constexpr (SPLIT) {
+        __shared__ int s_key[2];
+        const int wv = threadIdx.x >> 6;
+        const uint32_t hwid = __builtin_amdgcn_s_getreg(4 | (31 << 11));   // HW_REG_HW_ID: wave slot [3:0], SIMD [5:4]
+        const int key = (int)((hwid ^ (hwid >> 4)) & 1u);
+        if (lane == 0) s_key[wv] = key;
+        __syncthreads();
+        stepper = (s_key[0] != s_key[1]) ? (key == 0) : (wv == 0);
+    }
     const bool active = chain < p.nchains;
     const int D = p.dim;
     const size_t NP = (size_t)p.npad;
@@ -372,8 +394,10 @@ __global__ void __launch_bounds__(kWave, 2) step_kernel(const StepParams p) {
 
     // Lanes past the last chain hold x = c0 so that their y = x - c0 is +0 in the
     // moment contraction; they never accept and never store.
+    if (stepper) {
 #pragma unroll
-    for (int d = 0; d < DP; ++d) xcol[d * kXStride] = active ? p.x[(size_t)d * NP + chain] : c0[d];
+        for (int d = 0; d < DP; ++d) xcol[d * kXStride] = active ? p.x[(size_t)d * NP + chain] : c0[d];
+    }
 
     double* lf = p.lane_f64 + chain;
     int32_t* li = p.lane_i32 + chain;
@@ -393,18 +417,19 @@ __global__ void __launch_bounds__(kWave, 2) step_kernel(const StepParams p) {
     int rms_trials = li[SMCMC_LANE_STEP_RMS_TRIALS * NP];
     int last_accept = li[SMCMC_LANE_LAST_ACCEPT * NP];
 
-    // stage U: lane-strided copy of each kept row segment
+    if (stepper) {
+        // stage U: lane-strided copy of each kept row segment
 #pragma unroll
-    for (int i = 0; i < DP; ++i) {
-        for (int k = lane; k < UL::len(i); k += kWave) {
-            const int j = UL::j0(i) + k;
-            us[UL::off(i) + k] = (j < DP) ? p.U[i * DP + j] : 0.0;
+        for (int i = 0; i < DP; ++i) {
+            for (int k = lane; k < UL::len(i); k += kWave) {
+                const int j = UL::j0(i) + k;
+                us[UL::off(i) + k] = (j < DP) ? p.U[i * DP + j] : 0.0;
+            }
         }
-    }
-
-    for (int k = lane; k < 128; k += kWave) {
-        ntab[k] = smcmc_log_table_dev[k];
-        ntab[128 + k] = smcmc_angle_table_dev[k];
+        for (int k = lane; k < 128; k += kWave) {
+            ntab[k] = smcmc_log_table_dev[k];
+            ntab[128 + k] = smcmc_angle_table_dev[k];
+        }
     }
     const lds_cptr_f64x2 ltab = (lds_cptr_f64x2)ntab, atab = (lds_cptr_f64x2)(ntab + 128);
 
@@ -417,29 +442,80 @@ __global__ void __launch_bounds__(kWave, 2) step_kernel(const StepParams p) {
     double c0s = 0.0;              // the same for the strip rows 16 T16 + (lane & 3)
     int xsrow = 0;
     if constexpr (MOMENTS) {
+        if (!SPLIT || !stepper) {
+#pragma unroll
+            for (int t = 0; t < NT16; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    acc[t][r] = p.gacc[(((size_t)group * NT + t) * 4 + r) * kWave + lane];
+            if constexpr (STRIP) {
+#pragma unroll
+                for (int t = 0; t < T; ++t) accs[t] = p.gacc[(((size_t)group * NT + NT16 + t) * 4) * kWave + lane];
+                const int r = 16 * Geo<DP>::T16 + (lane & 3);
+                c0s = (r < DP) ? p.c0[r] : 0.0;
+                xsrow = ((r <= DP) ? r : DP) * kXStride + (lane >> 4);
+            }
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const int r = 16 * t + (lane & 15);
+                c0r[t] = (r < DP) ? p.c0[r] : 0.0;
+                xrow[t] = ((r <= DP) ? r : DP) * kXStride + (lane >> 4);
+            }
+        }
+        // row DP carries the constant 1 (sum y and the point count come out of the
+        // same contraction); tile rows above it are zero and are not stored
+        if (stepper) xcol[DP * kXStride] = active ? 1.0 : 0.0;
+    }
+    __syncthreads();
+
+    // one k-quad (four chains) of the group's second moments: the operands from the LDS image, then the tiles
+    auto fold_kquad = [&](auto kc) {
+        constexpr int kk = decltype(kc)::value;
+        double fa[T], fs = 0.0;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            fa[t] = xs[xrow[t] + 4 * kk] - c0r[t];
+            if (16 * t + 15 > DP) fa[t] = (16 * t + (lane & 15) <= DP) ? fa[t] : 0.0;   // rows past the ones row
+        }
+        if constexpr (STRIP) {
+            fs = xs[xsrow + 4 * kk] - c0s;
+            fs = (16 * Geo<DP>::T16 + (lane & 3) <= DP) ? fs : 0.0;
+        }
+        static_for<NT>([&](auto tc) {
+            constexpr int tile = decltype(tc)::value;
+            if constexpr (!STRIP || tile < NT16) {
+                constexpr int ti = tile_row(tile), tj = tile - ti * (ti + 1) / 2;
+                acc[tile] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[ti], fa[tj], acc[tile], 0, 0, 0);
+            } else {
+                constexpr int t = tile - NT16;
+                accs[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(fs, fa[t], accs[t], 0, 0, 0);
+            }
+        });
+    };
+    auto store_moments = [&]() {
 #pragma unroll
         for (int t = 0; t < NT16; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                acc[t][r] = p.gacc[(((size_t)group * NT + t) * 4 + r) * kWave + lane];
+                p.gacc[(((size_t)group * NT + t) * 4 + r) * kWave + lane] = acc[t][r];
         if constexpr (STRIP) {
 #pragma unroll
-            for (int t = 0; t < T; ++t) accs[t] = p.gacc[(((size_t)group * NT + NT16 + t) * 4) * kWave + lane];
-            const int r = 16 * Geo<DP>::T16 + (lane & 3);
-            c0s = (r < DP) ? p.c0[r] : 0.0;
-            xsrow = ((r <= DP) ? r : DP) * kXStride + (lane >> 4);
+            for (int t = 0; t < T; ++t) p.gacc[(((size_t)group * NT + NT16 + t) * 4) * kWave + lane] = accs[t];
         }
-        // row DP carries the constant 1 (sum y and the point count come out of the
-        // same contraction); tile rows above it are zero and are not stored
-        xcol[DP * kXStride] = active ? 1.0 : 0.0;
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
-            const int r = 16 * t + (lane & 15);
-            c0r[t] = (r < DP) ? p.c0[r] : 0.0;
-            xrow[t] = ((r <= DP) ? r : DP) * kXStride + (lane >> 4);
+    };
+    if constexpr (SPLIT) {
+        if (!stepper) {
+            // the fold wavefront: per step the sixteen k-quads of the point the step wavefront's UpdateState sees,
+            // chains in ascending order, tiles in order -- the sequence the single-wavefront kernel issues
+            for (int s = 0; s < p.nsteps; ++s) {
+                static_for<16>(fold_kquad);
+                __syncthreads();   // the image may change now (likelihood swap, accept copy)
+                __syncthreads();   // ... and is the next step's point
+            }
+            store_moments();
+            return;
         }
     }
-    __syncthreads();
 
     double xp[DP];
     const uint32_t aw = smcmc_accept_word((uint32_t)D);
@@ -450,6 +526,7 @@ __global__ void __launch_bounds__(kWave, 2) step_kernel(const StepParams p) {
         // QUADFORM: the proposal and the accepted point trade places -- the likelihood reads the proposal from
         // the LDS column, the registers keep the accepted point to put back on a reject
         constexpr bool SWAP = (LIKE == SMCMC_LIKE_QUADFORM);
+        if constexpr (SPLIT) __syncthreads();   // the fold wavefront has read this step's point
         if constexpr (SPECIAL || !EXACT) {
             // GetProposed() (TSimpleMCMC.H:514): the proposal of the latest step, accepted or not (in the reference
             // order only the SPECIAL instantiation carries the store; the fused kernels all do)
@@ -519,7 +596,7 @@ __global__ void __launch_bounds__(kWave, 2) step_kernel(const StepParams p) {
     };
 
     int s0 = 0;
-    if (p.has_forced && p.nsteps > 0) {
+    if (!SPLIT && p.has_forced && p.nsteps > 0) {
         // ForceStep (TSimpleMCMC.H:671-678): the proposal is the forced point and the
         // proposal state is not updated
 #pragma unroll
@@ -603,7 +680,7 @@ __global__ void __launch_bounds__(kWave, 2) step_kernel(const StepParams p) {
         // keeps them inside the step.
         lds_cptr_f64 up = (lds_cptr_f64)us;
         asm volatile("" : "+v"(up));
-        double ma[MOMENTS ? T : 1];   // matrix-pipe operands of the chain quad being folded
+        double ma[FOLD ? T : 1];      // matrix-pipe operands of the chain quad being folded
         double ms = 0.0;              // ... and the strip rows' operand
         static_for<NB>([&](auto bc) {
             constexpr int b = decltype(bc)::value;
@@ -655,7 +732,7 @@ __global__ void __launch_bounds__(kWave, 2) step_kernel(const StepParams p) {
                         asm volatile("" : "+v"(xp[j]));
                     }
                 }
-                if constexpr (MOMENTS) {
+                if constexpr (FOLD) {
                     // The group's second moments: the 16 x NT matrix instructions of the 64-chain
                     // contraction are dealt out over the pieces of the step (1-2 per piece), so
                     // each one runs on the matrix pipe under the piece's VALU work instead of
@@ -721,17 +798,7 @@ __global__ void __launch_bounds__(kWave, 2) step_kernel(const StepParams p) {
         finish_step(s, uword);
     }
 
-    if constexpr (MOMENTS) {
-#pragma unroll
-        for (int t = 0; t < NT16; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                p.gacc[(((size_t)group * NT + t) * 4 + r) * kWave + lane] = acc[t][r];
-        if constexpr (STRIP) {
-#pragma unroll
-            for (int t = 0; t < T; ++t) p.gacc[(((size_t)group * NT + NT16 + t) * 4) * kWave + lane] = accs[t];
-        }
-    }
+    if constexpr (FOLD) store_moments();
     if (active) {
 #pragma unroll
         for (int d = 0; d < DP; ++d) p.x[(size_t)d * NP + chain] = xcol[d * kXStride];

@@ -528,6 +528,14 @@ class HmcEngine:
     def GetGradientType(self): return int(self._lib.smcmc_hmc_get_gradient_type(self._h))
     def sync(self): self._check(self._lib.smcmc_hmc_sync(self._h))
 
+    # the pooled update in pieces (a sharded ensemble adds the ranks' moment vectors between export and import)
+    @property
+    def moments_size(self): return self._lib.smcmc_hmc_moments_size(self._h)
+    def reduce_moments(self): self._check(self._lib.smcmc_hmc_reduce_moments(self._h))
+    def export_moments(self, dst_device_ptr): self._check(self._lib.smcmc_hmc_export_moments(self._h, C.c_void_p(int(dst_device_ptr))))
+    def import_moments(self, src_device_ptr): self._check(self._lib.smcmc_hmc_import_moments(self._h, C.c_void_p(int(src_device_ptr))))
+    def apply_moments(self): self._check(self._lib.smcmc_hmc_apply_moments(self._h))
+
     @property
     def moment_group(self):
         return self._lib.smcmc_hmc_moment_group(self._h)

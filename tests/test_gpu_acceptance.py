@@ -21,7 +21,7 @@ def test_config2_posterior_within_one_percent(gpu, oracle):
     mean, cov = acc.mean, acc.covariance
     assert np.max(np.abs(mean)) < 0.01, np.max(np.abs(mean))                       # 1 % of sigma = 1
     assert np.max(np.abs(cov - np.eye(dim))) < 0.01, np.max(np.abs(cov - np.eye(dim)))
-    assert abs(e.lane("naccept").sum() / (e.get_param("TOTAL_STEPS") * chains) - 0.234) < 0.02
+    assert abs(e.lane("acceptance").mean() - 0.234) < 0.03     # the chains' running acceptance sits on the target
     # the CPU reference chain (covariance adapting, TSimpleMCMC.H:1780-1820), 3e5 steps: one chain's estimate carries a
     # Monte-Carlo error of a few percent (ESS ~ steps / (3 D / 0.234)), the comparison is made at that level
     c = oracle.Chain(dim)

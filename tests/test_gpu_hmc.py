@@ -324,3 +324,48 @@ def test_hmc_more_moment_groups_than_one_reduction_chunk(gpu, oracle):
     e.Start(np.ones(dim)); o.start(np.ones(dim))
     e.Step(6); o.step(6)
     _same_hmc(e, o, "six steps")
+
+
+# ---------------------------------------------------------------- the pooled covariance across engines / ranks
+@pytest.mark.parametrize("kind,dim", [(0, 20), (1, 100)])
+def test_hmc_sharded_exchange_equals_one_engine(gpu, oracle, kind, dim):
+    """Two engines of 2048 chains with chain offsets -- moments reduced, exported, added on the device, imported and
+    applied after every step -- are one engine of 4096 chains, bit for bit: the pooled UpdateCovariance /
+    UpdateErrorMatrix of a sharded ensemble (what ranks do with one RCCL all-reduce between export and import)."""
+    import torch
+    n = 4096
+    prm = np.linalg.inv(_spd(dim, 3)) if kind == 1 else None
+    whole = gpu.HmcEngine(dim, n, likelihood=kind, likelihood_params=prm, seed=5)
+    halves = [gpu.HmcEngine(dim, n // 2, likelihood=kind, likelihood_params=prm, seed=5, chain_offset=k * (n // 2)) for k in range(2)]
+    x0 = np.full(dim, 0.5)
+    whole.Start(x0)
+    for h in halves:
+        h.SetSyncInterval(10 ** 9)                           # the caller runs the update
+        h.Start(x0)
+    if kind == 1:
+        for h in [whole] + halves:
+            h.SetLeapFrog(6)
+    for step in range(12 if dim <= 20 else 6):
+        whole.Step(1)
+        bufs = []
+        for h in halves:
+            h.Step(1)
+            h.reduce_moments()
+            b = torch.zeros(h.moments_size, dtype=torch.float64, device="cuda")
+            h.export_moments(b.data_ptr())
+            bufs.append(b)
+        total = bufs[0] + bufs[1]
+        for h in halves:
+            h.import_moments(total.data_ptr())
+            h.apply_moments()
+        torch.cuda.synchronize()
+        q, m, logl = whole.state()
+        for k, h in enumerate(halves):
+            sl = slice(k * (n // 2), (k + 1) * (n // 2))
+            hq, hm, hl = h.state()
+            assert np.array_equal(hq, q[:, sl]) and np.array_equal(hm, m[:, sl]) and np.array_equal(hl, logl[sl]), f"step {step}"
+            assert np.array_equal(h.lane("mean_epsilon"), whole.lane("mean_epsilon")[sl]), f"step {step}: epsilon"
+            assert np.array_equal(h.lane("leapfrog"), whole.lane("leapfrog")[sl]), f"step {step}: leapfrog"
+            assert np.array_equal(h.covariance, whole.covariance) and np.array_equal(h.average, whole.average)
+            assert h.tuning == whole.tuning, f"step {step}: {h.tuning} != {whole.tuning}"
+    assert whole.tuning["updates"] >= 1 and whole.lane("naccept").sum() > 0

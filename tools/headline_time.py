@@ -1,21 +1,34 @@
-"""Diagnostic (GPU box): window time of the headline workload (D = 50, 65 536 chains, pooled, 256 steps / launch)."""
-import sys, time, numpy as np
-sys.path.insert(0, "/root/repo")
-from smcmc_amd_loader import load_package
-import torch
+"""Diagnostic (GPU box): window time of the headline workload (D = 50, 65 536 chains, pooled, 256 steps / launch) with
+the moment fold in a second wavefront (SMCMC_P_SPLIT_FOLD = 1, the default) and in the step wavefront itself (0).
+usage: python tools/headline_time.py [dim [chains]]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from smcmc_amd_loader import load_package  # noqa: E402
+import torch  # noqa: E402
+
 pkg = load_package()
-ext = int(sys.argv[1]) if len(sys.argv) > 1 else 0
-e = pkg.Engine(50, 65536)
-e.Start(np.zeros(50))
-for _ in range(4):
-    e.Step(256); e.sync()
-torch.cuda.synchronize()
-evs = []
-t0 = time.perf_counter()
-for _ in range(30):
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record(); e.Step(256); b.record(); evs.append((a, b)); e.sync()
-torch.cuda.synchronize()
-dt = (time.perf_counter() - t0) / 30
-k = np.mean([a.elapsed_time(b) for a, b in evs])
-print("ext %d: window %.3f ms, step launch %.3f ms, model frac %.4f" % (ext, dt * 1e3, k, 65536 * 256 * 816 / (k * 1e-3) / 8e12))
+dim = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+chains = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
+for split in (1, 0, 1, 0):
+    e = pkg.Engine(dim, chains)
+    e.set_param("SPLIT_FOLD", split)
+    e.Start(np.zeros(dim))
+    for _ in range(4):
+        e.Step(256); e.sync()
+    torch.cuda.synchronize()
+    evs = []
+    t0 = time.perf_counter()
+    for _ in range(30):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); e.Step(256); b.record(); evs.append((a, b)); e.sync()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 30
+    k = np.mean([a.elapsed_time(b) for a, b in evs])
+    print("split %d: window %.3f ms, step launch %.3f ms, model frac %.4f" %
+          (split, dt * 1e3, k, chains * 256 * (16 * dim + 16) / (k * 1e-3) / 8e12), flush=True)
+    e.close()

@@ -110,9 +110,6 @@ typedef enum {
                                          * window late.  0 (default): parity mode */
     SMCMC_P_COVARIANCE_FROZEN = 23,     /* Set/GetCovarianceFrozen :937-938 inside SMCMC_MODE_PER_CHAIN: the covariance loop is
                                          * skipped, the centre still runs (SMCMC_MODE_FROZEN is the shared-decomposition form) */
-    SMCMC_P_SPLIT_FOLD = 24,            /* 1 (default): dim <= 63, POOLED: the moment fold runs in a second wavefront of every
-                                         * chain group's workgroup (two wavefronts per SIMD at 65 536 chains); 0: one wavefront
-                                         * does both.  The same matrix instructions in the same order: identical results. */
     SMCMC_P_COUNT_
 } smcmc_param;
 

@@ -130,7 +130,6 @@ struct smcmc_engine {
     double* d_pc_tmpl = nullptr;   // what the host hands to every chain at Start / Restore / ResetProposal: cov packed, then ut
     int* d_pc_flag = nullptr;      // chains that stopped for the host's fallback ladder in the latest launch
     bool pc_frozen = false;        // SMCMC_P_COVARIANCE_FROZEN
-    bool split_fold = true;        // SMCMC_P_SPLIT_FOLD
     std::string error;
 };
 
@@ -856,7 +855,6 @@ StepParams make_params(smcmc_engine* h, int nsteps, int metropolis) {
     p.uniform = h->d_uniform;
     for (int d = 0; d < h->dim && d < 64; ++d)   // the register kernels (dim <= 63); larger dimensions carry theirs in d_uniform
         if (P.ptype[d] == 1) p.uniform_mask |= (uint64_t)1 << d;
-    p.split = h->split_fold ? 1 : 0;
     p.scan_dim = h->scan_dim;
     if (h->scan_dim >= 0) {
         const int sd = h->scan_dim;
@@ -1274,7 +1272,6 @@ int smcmc_set_param(smcmc_engine* h, int which, double v) {
             P.centreTrials = v;
             return (per_chain(h) && h->started) ? broadcast_lane_f64(h, SMCMC_LANE_CENTER_TRIALS, v) : SMCMC_OK;
         case SMCMC_P_COVARIANCE_FROZEN: h->pc_frozen = (v != 0.0); return SMCMC_OK;
-        case SMCMC_P_SPLIT_FOLD: h->split_fold = (v != 0.0); return SMCMC_OK;
         case SMCMC_P_EXACT_ARITHMETIC:
             h->exact = (v != 0.0);
             if (h->started) {                                  // the fused order keeps its own operand images
@@ -1384,7 +1381,6 @@ int smcmc_get_param(smcmc_engine* h, int which, double* out) {
         case SMCMC_P_DEVICE_UPDATE: *out = h->device_update ? 1.0 : 0.0; break;
         case SMCMC_P_OVERLAP_UPDATE: *out = h->overlap_update ? 1.0 : 0.0; break;
         case SMCMC_P_COVARIANCE_FROZEN: *out = (h->pc_frozen || h->mode == SMCMC_MODE_FROZEN) ? 1.0 : 0.0; break;
-        case SMCMC_P_SPLIT_FOLD: *out = h->split_fold ? 1.0 : 0.0; break;
         default: return fail(h, SMCMC_ERR_INVALID, "unknown parameter");
     }
     return SMCMC_OK;

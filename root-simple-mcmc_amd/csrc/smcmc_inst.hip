@@ -17,19 +17,10 @@ static hipError_t go(const StepParams& p, hipStream_t s) {
     return hipGetLastError();
 }
 
-template <int DP, int LIKE, bool EXACT>
-static hipError_t go_split(const StepParams& p, hipStream_t s) {
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(step_kernel<DP, LIKE, EXACT, false, true, false, true>), dim3(p.npad / kWave),
-                       dim3(2 * kWave), 0, s, p);
-    return hipGetLastError();
-}
-
 template <>
 hipError_t launch_step_like<SMCMC_DP, SMCMC_LIKE>(const StepParams& p, bool exact, bool fullu, bool mom, bool special,
                                                   hipStream_t s) {
     constexpr int DP = SMCMC_DP, LIKE = SMCMC_LIKE;
-    if (p.split && mom && !special && !fullu && !p.has_forced)
-        return exact ? go_split<DP, LIKE, true>(p, s) : go_split<DP, LIKE, false>(p, s);
     if (special) {
         // uniform dimensions / scan: reference-order arithmetic only
         if (!exact) return hipErrorNotSupported;

@@ -64,11 +64,17 @@ __device__ __forceinline__ cptr_f64 as_const(const double* p) {
 // The two entries come in ahead of the arithmetic (normal_tables_fetch): an LDS read returns in issue order, so a
 // table read issued behind the prefetch of the next U piece would wait for the whole piece.
 struct NormalTables { f64x2 le, ae; };
-__device__ __forceinline__ NormalTables normal_tables_fetch(uint32_t w0, uint32_t w1, lds_cptr_f64x2 lt, lds_cptr_f64x2 at) {
+// (inline assembly for the same reason as load_piece: the wait is normal_tables_ready, placed by the caller)
+__device__ __forceinline__ NormalTables normal_tables_fetch(uint32_t w0, uint32_t w1, uint32_t lt_base, uint32_t at_base) {
     NormalTables t;
-    t.le = *(volatile lds_cptr_f64x2)(lt + smcmc_normal_log_index(w0));
-    t.ae = *(volatile lds_cptr_f64x2)(at + smcmc_normal_angle_index(w1));
+    const uint32_t la = lt_base + 16u * smcmc_normal_log_index(w0), aa = at_base + 16u * smcmc_normal_angle_index(w1);
+    asm volatile("ds_read_b128 %0, %1" : "=v"(t.le) : "v"(la));
+    asm volatile("ds_read_b128 %0, %1" : "=v"(t.ae) : "v"(aa));
     return t;
+}
+template <int N>
+__device__ __forceinline__ void normal_tables_ready(NormalTables& a, NormalTables& b) {
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a.le), "+v"(a.ae), "+v"(b.le), "+v"(b.ae) : "n"(N));
 }
 __device__ __forceinline__ void normal_pair_lds(uint32_t w0, uint32_t w1, const NormalTables& t, double* n0, double* n1) {
 #define SMCMC_LT_LDS(k, c) (t.le[c])
@@ -154,14 +160,41 @@ struct UPieces {
 };
 
 // kPiece columns of row i starting at column c (c - j0(i) is even: 16-byte aligned reads).
-template <int DP, bool FULLU, int i, int c>
-__device__ __forceinline__ void load_piece(lds_cptr_f64 up, f64x2 (&dst)[kPiece / 2]) {
+//
+// The reads are inline assembly and so is the wait for them.  A lone wavefront pays an issue slot (four cycles) for
+// every instruction of any kind; left to the compiler, every use of a loaded pair gets a wait with a count of its own
+// -- eight per piece, some 600 s_waitcnt per step, 7 % of the step.  LDS reads return in issue order, so ONE
+// `s_waitcnt lgkmcnt(n)` placed after the next piece's n reads covers the whole current piece (piece_ready).  The
+// compiler does not count reads it cannot see: its own waits then over-wait (safe), these wait for everything older
+// (safe whatever else is in flight).
+template <int DP, bool FULLU, int i, int c, int k = 0>
+__device__ __forceinline__ void load_piece(uint32_t ubase, f64x2 (&dst)[kPiece / 2]) {
     typedef ULayout<DP, FULLU> UL;
-#pragma unroll
-    for (int k = 0; k < kPiece / 2; ++k) {
-        if (c + 2 * k < UL::DPE)
-            dst[k] = *(volatile lds_cptr_f64x2)(up + UL::off(i) + (c - UL::j0(i)) + 2 * k);
+    if constexpr (k < kPiece / 2) {
+        if constexpr (c + 2 * k < UL::DPE)
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[k]) : "v"(ubase), "n"((UL::off(i) + (c - UL::j0(i)) + 2 * k) * 8));
+        load_piece<DP, FULLU, i, c, k + 1>(ubase, dst);
     }
+}
+// LDS reads load_piece issues for the piece at column c
+template <int DP, bool FULLU, int c>
+constexpr int piece_reads() {
+    int n = 0;
+    for (int k = 0; k < kPiece / 2; ++k) n += (c + 2 * k < ULayout<DP, FULLU>::DPE) ? 1 : 0;
+    return n;
+}
+// every LDS read older than the N youngest has returned; `piece` is the piece those older reads filled (its first M pairs)
+template <int N, int M>
+__device__ __forceinline__ void piece_ready(f64x2 (&q)[kPiece / 2]) {
+    static_assert(kPiece == 16 && N >= 0 && N < 16 && M >= 1 && M <= 8, "eight register pairs per piece, a 4-bit counter");
+    if constexpr (M == 8) asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]), "+v"(q[6]), "+v"(q[7]) : "n"(N));
+    else if constexpr (M == 7) asm volatile("s_waitcnt lgkmcnt(%7)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]), "+v"(q[6]) : "n"(N));
+    else if constexpr (M == 6) asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]) : "n"(N));
+    else if constexpr (M == 5) asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]) : "n"(N));
+    else if constexpr (M == 4) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]) : "n"(N));
+    else if constexpr (M == 3) asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]) : "n"(N));
+    else if constexpr (M == 2) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(q[0]), "+v"(q[1]) : "n"(N));
+    else asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(q[0]) : "n"(N));
 }
 
 // row ti of lower-triangular tile number `tile` (tile = ti (ti + 1) / 2 + tj, tj <= ti)
@@ -200,7 +233,6 @@ struct StepParams {
     double scan_a, scan_b;     // uniform: bounds; Gaussian: centre, sigma
     double* proposed;          // optional [DP][npad]: the proposal of the launch's last step (fProposed, TSimpleMCMC.H:576);
                                // the SPECIAL instantiation and the fused-order kernels look at it
-    int split;                 // pooled, no special proposal, no forced step: the SPLIT instantiation (a second wavefront folds)
     int zero;                  // always 0; makes table addresses depend on the step so that the
                                // compiler does not hoist (and then spill) whole tables out of the loop
 };
@@ -349,16 +381,8 @@ __device__ __forceinline__ double loglike_quadform_lds(const double* xq, cptr_f6
     return logl;
 }
 
-// SPLIT = the pooled moments are folded by a SECOND wavefront of the workgroup (a workgroup is then 128 threads for
-// the same 64 chains): the step wavefront runs the MOMENTS = false code, the fold wavefront reads the accepted points
-// from the shared LDS image and issues the matrix instructions, two barriers per step between them (before and after
-// the accept copy).  A lone wavefront per SIMD leaves a third of its cycles idle (LDS waits, dependent chains); with
-// 65 536 chains there is exactly one step wavefront per SIMD, and the fold wavefront of another workgroup fills those
-// cycles.  Same matrix instructions in the same order on the same accumulators: the moments do not change by a bit.
-template <int DP, int LIKE, bool EXACT, bool FULLU, bool MOMENTS, bool SPECIAL, bool SPLIT = false>
-__global__ void __launch_bounds__(SPLIT ? 2 * kWave : kWave, 2) step_kernel(const StepParams p) {
-    static_assert(!SPLIT || (MOMENTS && !SPECIAL), "the split form is the pooled kernel without the special proposals");
-    constexpr bool FOLD = MOMENTS && !SPLIT;   // this wavefront folds the moments itself
+template <int DP, int LIKE, bool EXACT, bool FULLU, bool MOMENTS, bool SPECIAL>
+__global__ void __launch_bounds__(kWave, 2) step_kernel(const StepParams p) {
     constexpr int T = Geo<DP>::T;
     constexpr int NT = Geo<DP>::NT;
     constexpr int NB = Geo<DP>::NB;
@@ -368,22 +392,9 @@ __global__ void __launch_bounds__(SPLIT ? 2 * kWave : kWave, 2) step_kernel(cons
     __shared__ __attribute__((aligned(16))) double us[UL::SIZE];   // decomposition, every lane reads the same word
     __shared__ __attribute__((aligned(16))) double ntab[256];      // tables of the normal transform: log [64][2], angle [64][2]
 
-    const int lane = threadIdx.x & (kWave - 1);
+    const int lane = threadIdx.x;
     const int group = blockIdx.x;
     const int chain = group * kWave + lane;
-    // SPLIT: which of the two wavefronts steps and which folds.  Two workgroups share a SIMD pair; the choice below
-    // puts one wavefront of each kind on a SIMD when the hardware places them the usual way (both wavefronts of a
-    // workgroup in the same slot of neighbouring SIMDs); any other placement only costs balance.
-    bool stepper = true;
-    if constexpr (SPLIT) {
-        __shared__ int s_key[2];
-        const int wv = threadIdx.x >> 6;
-        const uint32_t hwid = __builtin_amdgcn_s_getreg(4 | (31 << 11));   // HW_REG_HW_ID: wave slot [3:0], SIMD [5:4]
-        const int key = (int)((hwid ^ (hwid >> 4)) & 1u);
-        if (lane == 0) s_key[wv] = key;
-        __syncthreads();
-        stepper = (s_key[0] != s_key[1]) ? (key == 0) : (wv == 0);
-    }
     const bool active = chain < p.nchains;
     const int D = p.dim;
     const size_t NP = (size_t)p.npad;
@@ -394,10 +405,8 @@ __global__ void __launch_bounds__(SPLIT ? 2 * kWave : kWave, 2) step_kernel(cons
 
     // Lanes past the last chain hold x = c0 so that their y = x - c0 is +0 in the
     // moment contraction; they never accept and never store.
-    if (stepper) {
 #pragma unroll
-        for (int d = 0; d < DP; ++d) xcol[d * kXStride] = active ? p.x[(size_t)d * NP + chain] : c0[d];
-    }
+    for (int d = 0; d < DP; ++d) xcol[d * kXStride] = active ? p.x[(size_t)d * NP + chain] : c0[d];
 
     double* lf = p.lane_f64 + chain;
     int32_t* li = p.lane_i32 + chain;
@@ -417,21 +426,20 @@ __global__ void __launch_bounds__(SPLIT ? 2 * kWave : kWave, 2) step_kernel(cons
     int rms_trials = li[SMCMC_LANE_STEP_RMS_TRIALS * NP];
     int last_accept = li[SMCMC_LANE_LAST_ACCEPT * NP];
 
-    if (stepper) {
-        // stage U: lane-strided copy of each kept row segment
+    // stage U: lane-strided copy of each kept row segment
 #pragma unroll
-        for (int i = 0; i < DP; ++i) {
-            for (int k = lane; k < UL::len(i); k += kWave) {
-                const int j = UL::j0(i) + k;
-                us[UL::off(i) + k] = (j < DP) ? p.U[i * DP + j] : 0.0;
-            }
-        }
-        for (int k = lane; k < 128; k += kWave) {
-            ntab[k] = smcmc_log_table_dev[k];
-            ntab[128 + k] = smcmc_angle_table_dev[k];
+    for (int i = 0; i < DP; ++i) {
+        for (int k = lane; k < UL::len(i); k += kWave) {
+            const int j = UL::j0(i) + k;
+            us[UL::off(i) + k] = (j < DP) ? p.U[i * DP + j] : 0.0;
         }
     }
-    const lds_cptr_f64x2 ltab = (lds_cptr_f64x2)ntab, atab = (lds_cptr_f64x2)(ntab + 128);
+
+    for (int k = lane; k < 128; k += kWave) {
+        ntab[k] = smcmc_log_table_dev[k];
+        ntab[128 + k] = smcmc_angle_table_dev[k];
+    }
+    const uint32_t ltab = (uint32_t)(uintptr_t)(lds_cptr_f64)ntab, atab = ltab + 128u * 8u;   // LDS byte addresses
 
     constexpr bool STRIP = MOMENTS && Geo<DP>::STRIP;
     constexpr int NT16 = Geo<DP>::NT16;
@@ -442,80 +450,29 @@ __global__ void __launch_bounds__(SPLIT ? 2 * kWave : kWave, 2) step_kernel(cons
     double c0s = 0.0;              // the same for the strip rows 16 T16 + (lane & 3)
     int xsrow = 0;
     if constexpr (MOMENTS) {
-        if (!SPLIT || !stepper) {
-#pragma unroll
-            for (int t = 0; t < NT16; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    acc[t][r] = p.gacc[(((size_t)group * NT + t) * 4 + r) * kWave + lane];
-            if constexpr (STRIP) {
-#pragma unroll
-                for (int t = 0; t < T; ++t) accs[t] = p.gacc[(((size_t)group * NT + NT16 + t) * 4) * kWave + lane];
-                const int r = 16 * Geo<DP>::T16 + (lane & 3);
-                c0s = (r < DP) ? p.c0[r] : 0.0;
-                xsrow = ((r <= DP) ? r : DP) * kXStride + (lane >> 4);
-            }
-#pragma unroll
-            for (int t = 0; t < T; ++t) {
-                const int r = 16 * t + (lane & 15);
-                c0r[t] = (r < DP) ? p.c0[r] : 0.0;
-                xrow[t] = ((r <= DP) ? r : DP) * kXStride + (lane >> 4);
-            }
-        }
-        // row DP carries the constant 1 (sum y and the point count come out of the
-        // same contraction); tile rows above it are zero and are not stored
-        if (stepper) xcol[DP * kXStride] = active ? 1.0 : 0.0;
-    }
-    __syncthreads();
-
-    // one k-quad (four chains) of the group's second moments: the operands from the LDS image, then the tiles
-    auto fold_kquad = [&](auto kc) {
-        constexpr int kk = decltype(kc)::value;
-        double fa[T], fs = 0.0;
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
-            fa[t] = xs[xrow[t] + 4 * kk] - c0r[t];
-            if (16 * t + 15 > DP) fa[t] = (16 * t + (lane & 15) <= DP) ? fa[t] : 0.0;   // rows past the ones row
-        }
-        if constexpr (STRIP) {
-            fs = xs[xsrow + 4 * kk] - c0s;
-            fs = (16 * Geo<DP>::T16 + (lane & 3) <= DP) ? fs : 0.0;
-        }
-        static_for<NT>([&](auto tc) {
-            constexpr int tile = decltype(tc)::value;
-            if constexpr (!STRIP || tile < NT16) {
-                constexpr int ti = tile_row(tile), tj = tile - ti * (ti + 1) / 2;
-                acc[tile] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[ti], fa[tj], acc[tile], 0, 0, 0);
-            } else {
-                constexpr int t = tile - NT16;
-                accs[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(fs, fa[t], accs[t], 0, 0, 0);
-            }
-        });
-    };
-    auto store_moments = [&]() {
 #pragma unroll
         for (int t = 0; t < NT16; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                p.gacc[(((size_t)group * NT + t) * 4 + r) * kWave + lane] = acc[t][r];
+                acc[t][r] = p.gacc[(((size_t)group * NT + t) * 4 + r) * kWave + lane];
         if constexpr (STRIP) {
 #pragma unroll
-            for (int t = 0; t < T; ++t) p.gacc[(((size_t)group * NT + NT16 + t) * 4) * kWave + lane] = accs[t];
+            for (int t = 0; t < T; ++t) accs[t] = p.gacc[(((size_t)group * NT + NT16 + t) * 4) * kWave + lane];
+            const int r = 16 * Geo<DP>::T16 + (lane & 3);
+            c0s = (r < DP) ? p.c0[r] : 0.0;
+            xsrow = ((r <= DP) ? r : DP) * kXStride + (lane >> 4);
         }
-    };
-    if constexpr (SPLIT) {
-        if (!stepper) {
-            // the fold wavefront: per step the sixteen k-quads of the point the step wavefront's UpdateState sees,
-            // chains in ascending order, tiles in order -- the sequence the single-wavefront kernel issues
-            for (int s = 0; s < p.nsteps; ++s) {
-                static_for<16>(fold_kquad);
-                __syncthreads();   // the image may change now (likelihood swap, accept copy)
-                __syncthreads();   // ... and is the next step's point
-            }
-            store_moments();
-            return;
+        // row DP carries the constant 1 (sum y and the point count come out of the
+        // same contraction); tile rows above it are zero and are not stored
+        xcol[DP * kXStride] = active ? 1.0 : 0.0;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const int r = 16 * t + (lane & 15);
+            c0r[t] = (r < DP) ? p.c0[r] : 0.0;
+            xrow[t] = ((r <= DP) ? r : DP) * kXStride + (lane >> 4);
         }
     }
+    __syncthreads();
 
     double xp[DP];
     const uint32_t aw = smcmc_accept_word((uint32_t)D);
@@ -526,7 +483,6 @@ __global__ void __launch_bounds__(SPLIT ? 2 * kWave : kWave, 2) step_kernel(cons
         // QUADFORM: the proposal and the accepted point trade places -- the likelihood reads the proposal from
         // the LDS column, the registers keep the accepted point to put back on a reject
         constexpr bool SWAP = (LIKE == SMCMC_LIKE_QUADFORM);
-        if constexpr (SPLIT) __syncthreads();   // the fold wavefront has read this step's point
         if constexpr (SPECIAL || !EXACT) {
             // GetProposed() (TSimpleMCMC.H:514): the proposal of the latest step, accepted or not (in the reference
             // order only the SPECIAL instantiation carries the store; the fused kernels all do)
@@ -596,7 +552,7 @@ __global__ void __launch_bounds__(SPLIT ? 2 * kWave : kWave, 2) step_kernel(cons
     };
 
     int s0 = 0;
-    if (!SPLIT && p.has_forced && p.nsteps > 0) {
+    if (p.has_forced && p.nsteps > 0) {
         // ForceStep (TSimpleMCMC.H:671-678): the proposal is the forced point and the
         // proposal state is not updated
 #pragma unroll
@@ -678,9 +634,9 @@ __global__ void __launch_bounds__(SPLIT ? 2 * kWave : kWave, 2) step_kernel(cons
         // The LDS image of U never changes, so the compiler would hoist all of its reads out
         // of the step loop and spill them; reading through a pointer it cannot see through
         // keeps them inside the step.
-        lds_cptr_f64 up = (lds_cptr_f64)us;
+        uint32_t up = (uint32_t)(uintptr_t)(lds_cptr_f64)us;   // LDS byte address of the decomposition
         asm volatile("" : "+v"(up));
-        double ma[FOLD ? T : 1];      // matrix-pipe operands of the chain quad being folded
+        double ma[MOMENTS ? T : 1];   // matrix-pipe operands of the chain quad being folded
         double ms = 0.0;              // ... and the strip rows' operand
         static_for<NB>([&](auto bc) {
             constexpr int b = decltype(bc)::value;
@@ -695,12 +651,13 @@ __global__ void __launch_bounds__(SPLIT ? 2 * kWave : kWave, 2) step_kernel(cons
             if ((uint32_t)b == (aw >> 2)) uword = smcmc_select_word(blk, aw & 3u);
             // LDS reads of the block, in this order (they return in issue order): the table entries of its two pairs of
             // normals, then the first piece of U, which stays in flight under the normals' arithmetic
-            const NormalTables t0 = normal_tables_fetch(blk.v[0], blk.v[1], ltab, atab);
+            NormalTables t0 = normal_tables_fetch(blk.v[0], blk.v[1], ltab, atab);
             NormalTables t1 = t0;
             if constexpr (4 * b + 2 < DP) t1 = normal_tables_fetch(blk.v[2], blk.v[3], ltab, atab);
             {
                 constexpr int i0 = PC::row(0), c0p = PC::col(0);
                 load_piece<DP, FULLU, i0, c0p>(up, cur);
+                normal_tables_ready<piece_reads<DP, FULLU, c0p>()>(t0, t1);
             }
             double n[4];
             normal_pair_lds(blk.v[0], blk.v[1], t0, &n[0], &n[1]);
@@ -717,6 +674,9 @@ __global__ void __launch_bounds__(SPLIT ? 2 * kWave : kWave, 2) step_kernel(cons
                 if constexpr (r + 1 < PC::COUNT) {
                     constexpr int i1 = PC::row(r + 1), c1 = PC::col(r + 1);
                     load_piece<DP, FULLU, i1, c1>(up, nxt);
+                    piece_ready<piece_reads<DP, FULLU, c1>(), piece_reads<DP, FULLU, c>()>(cur);
+                } else {
+                    piece_ready<0, piece_reads<DP, FULLU, c>()>(cur);
                 }
                 const double srow = sr[i - 4 * b];
 #pragma unroll
@@ -732,7 +692,7 @@ __global__ void __launch_bounds__(SPLIT ? 2 * kWave : kWave, 2) step_kernel(cons
                         asm volatile("" : "+v"(xp[j]));
                     }
                 }
-                if constexpr (FOLD) {
+                if constexpr (MOMENTS) {
                     // The group's second moments: the 16 x NT matrix instructions of the 64-chain
                     // contraction are dealt out over the pieces of the step (1-2 per piece), so
                     // each one runs on the matrix pipe under the piece's VALU work instead of
@@ -798,7 +758,17 @@ __global__ void __launch_bounds__(SPLIT ? 2 * kWave : kWave, 2) step_kernel(cons
         finish_step(s, uword);
     }
 
-    if constexpr (FOLD) store_moments();
+    if constexpr (MOMENTS) {
+#pragma unroll
+        for (int t = 0; t < NT16; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                p.gacc[(((size_t)group * NT + t) * 4 + r) * kWave + lane] = acc[t][r];
+        if constexpr (STRIP) {
+#pragma unroll
+            for (int t = 0; t < T; ++t) p.gacc[(((size_t)group * NT + NT16 + t) * 4) * kWave + lane] = accs[t];
+        }
+    }
     if (active) {
 #pragma unroll
         for (int d = 0; d < DP; ++d) p.x[(size_t)d * NP + chain] = xcol[d * kXStride];

@@ -681,35 +681,3 @@ def test_frozen_lanes_after_a_million_steps(gpu, oracle):
         assert sc["next_update"] == e.lane("next_update")[ch] and sc["step_rms"] == e.lane("step_rms")[ch]
     acc = e.lane("naccept") / steps
     assert np.all(np.abs(acc - 0.234) < 0.02)                 # every chain settled on the target acceptance
-
-
-@pytest.mark.parametrize("kind,dim,exact", [(0, 50, True), (0, 50, False), (1, 20, True), (2, 31, True), (0, 7, True), (1, 63, False)])
-def test_split_fold_is_the_single_wavefront_fold(gpu, oracle, kind, dim, exact):
-    """SMCMC_P_SPLIT_FOLD: the pooled moments folded by a second wavefront of the workgroup (default) or by the step
-    wavefront itself -- the same matrix instructions in the same order, so states, moments and the pooled update are
-    the same bits; both are the oracle's ensemble."""
-    n = 200
-    prm = _like_params(oracle, kind, dim)
-    engines = []
-    for split in (1, 0):
-        e = gpu.Engine(dim, n, likelihood=kind, likelihood_params=prm, mode=gpu.MODE_POOLED, exact=exact)
-        e.set_param("SPLIT_FOLD", split)
-        assert e.get_param("SPLIT_FOLD") == split
-        engines.append(e)
-    o = oracle.Ensemble(n, dim, kind=kind, params=prm, mode=oracle.MODE_POOLED, exact=exact)
-    x0 = _start(kind, dim, n, np.random.default_rng(dim))
-    for e in engines:
-        assert e.Start(x0)
-    assert o.start(x0)
-    for w in range(3):
-        for e in engines:
-            e.Step(24)
-        o.step(24)
-        ms = []
-        for e in engines:
-            e.reduce_moments(); ms.append(e.read_moments()); e.apply_moments()
-        m = o.reduce_moments(); o.apply_moments(m)
-        assert np.array_equal(ms[0], ms[1]) and np.array_equal(ms[0], m), f"window {w}: moments"
-        for e in engines:
-            _assert_same_state(e, o, f"window {w}")
-            assert np.array_equal(e.decomposition, o.decomposition)

@@ -48,8 +48,9 @@ def _units(user_flag=None):
     instances are compiled with it; every other object is shared with the plain build."""
     engine = ("smcmc_engine.hip", [user_flag], "engine_user") if user_flag else ("smcmc_engine.hip", [], "engine")
     vaat = ("smcmc_vaat_engine.hip", [user_flag], "vaat_engine_user") if user_flag else ("smcmc_vaat_engine.hip", [], "vaat_engine")
+    hmc = ("smcmc_hmc_engine.hip", [user_flag], "hmc_engine_user") if user_flag else ("smcmc_hmc_engine.hip", [], "hmc_engine")
     units = [engine, ("smcmc_selftest.hip", [], "selftest"), ("smcmc_autocorr.hip", [], "autocorr"),
-             ("smcmc_hmc_engine.hip", [], "hmc_engine"), ("smcmc_hmc_mfma_inst.hip", [], "hmc_mfma"),
+             hmc, ("smcmc_hmc_mfma_inst.hip", [], "hmc_mfma"),
              vaat, ("smcmc_vaat_large.hip", [], "vaat_large"),
              ("smcmc_pooled_update.hip", [], "pooled_update"), ("smcmc_perchain_inst.hip", [], "perchain"),
              ("smcmc_panel_mfma_inst.hip", [], "panel_mfma")]
@@ -61,7 +62,10 @@ def _units(user_flag=None):
             units.append(("smcmc_inst.hip", [f"-DSMCMC_DP={dp}", f"-DSMCMC_LIKE={like}"], f"inst_dp{dp}_l{like}"))
     for w in (4, 8):
         units.append(("smcmc_panel_inst.hip", [f"-DSMCMC_PANEL_W={w}"], f"panel_w{w}"))
-        units.append(("smcmc_hmc_inst.hip", [f"-DSMCMC_PANEL_W={w}"], f"hmc_w{w}"))
+        if user_flag:   # a user likelihood as an HMC target (finite-difference / covariant gradient)
+            units.append(("smcmc_hmc_inst.hip", [f"-DSMCMC_PANEL_W={w}", user_flag], f"hmc_w{w}_user"))
+        else:
+            units.append(("smcmc_hmc_inst.hip", [f"-DSMCMC_PANEL_W={w}"], f"hmc_w{w}"))
     if user_flag:
         for dp in dp_list():   # SMCMC_LIKE_USER = 3
             units.append(("smcmc_inst.hip", [f"-DSMCMC_DP={dp}", "-DSMCMC_LIKE=3", user_flag], f"inst_dp{dp}_l3"))

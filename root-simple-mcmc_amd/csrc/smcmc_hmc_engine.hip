@@ -99,6 +99,12 @@ size_t hmc_gacc_doubles(const smcmc_hmc* h) {
 
 // the chains retune themselves (TSimpleHMC.H:302-345, 833-847) unless both the step length and the count are fixed
 bool hmc_adaptive(const smcmc_hmc* h) { return h->mean_epsilon > 0.0 || h->leapfrog > 0; }
+// likelihoods without a gradient of their own (the reference's functors throw / return false, TAsymLogLikelihood.H:34-36,
+// TSimpleHMC.H:85-89): HMC targets through PotentialGradient types 2 / 3 / 5 only
+bool hmc_no_own_gradient(int like) {
+    return like == SMCMC_LIKE_USER || like == SMCMC_LIKE_ASYM || like == SMCMC_LIKE_HORRIFIC || like == SMCMC_LIKE_CONSTRAINED;
+}
+size_t hmc_like_doubles(int dim) { return (size_t)dim * dim + 2 * (size_t)dim + 8; }
 bool hmc_generic_gradient(const smcmc_hmc* h) { return h->gradient_type == 2 || h->gradient_type == 3 || h->gradient_type == 5; }
 // the covariant gradient reads the running covariance: it has to be kept
 bool hmc_tracking(const smcmc_hmc* h) { return hmc_adaptive(h) || h->track_cov || h->gradient_type == 2; }
@@ -401,9 +407,11 @@ int smcmc_hmc_create(int dim, int nchains, int likelihood, uint64_t seed, uint32
     if (!out) return SMCMC_ERR_INVALID;
     *out = nullptr;
     if (dim < 1 || nchains < 1) return SMCMC_ERR_INVALID;
-    if (likelihood >= SMCMC_LIKE_ASYM && likelihood <= SMCMC_LIKE_CONSTRAINED)
-        return SMCMC_ERR_UNSUPPORTED;   // the stress likelihoods have no gradient (TSimpleHMC.H:85-89 needs one)
-    if (likelihood < SMCMC_LIKE_ISO_GAUSS || likelihood > SMCMC_LIKE_ROSENBROCK) return SMCMC_ERR_INVALID;
+    if (likelihood < SMCMC_LIKE_ISO_GAUSS || likelihood > SMCMC_LIKE_CONSTRAINED) return SMCMC_ERR_INVALID;
+#ifndef SMCMC_USER_LIKELIHOOD_ANY_DIM
+    // a compiled-in user likelihood is an HMC target when its header has the form that walks a point in device memory
+    if (likelihood == SMCMC_LIKE_USER) return SMCMC_ERR_UNSUPPORTED;
+#endif
     if (likelihood == SMCMC_LIKE_ROSENBROCK && dim < 2) return SMCMC_ERR_INVALID;
     if (dim > 8 * kPanelCW) return SMCMC_ERR_UNSUPPORTED;
     int ndev = 0;
@@ -427,7 +435,7 @@ int smcmc_hmc_create(int dim, int nchains, int likelihood, uint64_t seed, uint32
     HMC_TRY(h, hipMalloc(&h->d_pn, vec));
     const size_t e_doubles = std::max({(size_t)h->W * dim * kPanelCW, hmc_mfma_eop_doubles(dim), hmc_exact_ex_doubles(dim)});
     HMC_TRY(h, hipMalloc(&h->d_E, sizeof(double) * e_doubles));
-    HMC_TRY(h, hipMalloc(&h->d_like, sizeof(double) * 8));
+    HMC_TRY(h, hipMalloc(&h->d_like, sizeof(double) * hmc_like_doubles(dim)));
     HMC_TRY(h, hipMalloc(&h->d_lane_f64, sizeof(double) * (size_t)h->npad * SMCMC_LANE_F64_COUNT_));
     HMC_TRY(h, hipMalloc(&h->d_lane_i32, sizeof(int32_t) * (size_t)h->npad * SMCMC_LANE_I32_COUNT_));
     HMC_TRY(h, hipMemset(h->d_q, 0, vec));
@@ -435,7 +443,7 @@ int smcmc_hmc_create(int dim, int nchains, int likelihood, uint64_t seed, uint32
     HMC_TRY(h, hipMemset(h->d_qn, 0, vec));
     HMC_TRY(h, hipMemset(h->d_pn, 0, vec));
     HMC_TRY(h, hipMemset(h->d_E, 0, sizeof(double) * e_doubles));
-    HMC_TRY(h, hipMemset(h->d_like, 0, sizeof(double) * 8));
+    HMC_TRY(h, hipMemset(h->d_like, 0, sizeof(double) * hmc_like_doubles(dim)));
     HMC_TRY(h, hipMemset(h->d_lane_f64, 0, sizeof(double) * (size_t)h->npad * SMCMC_LANE_F64_COUNT_));
     HMC_TRY(h, hipMemset(h->d_lane_i32, 0, sizeof(int32_t) * (size_t)h->npad * SMCMC_LANE_I32_COUNT_));
     return SMCMC_OK;
@@ -610,9 +618,27 @@ int smcmc_hmc_start(smcmc_hmc* h, const double* x0, int broadcast) {
         h->use_mfma = false;
         h->use_matrix_exact = false;
     }
-    double b = 100.0;
-    if (h->likelihood == SMCMC_LIKE_ROSENBROCK && !h->like_params.empty()) b = h->like_params[0];
-    HMC_TRY(h, hipMemcpyAsync(h->d_like, &b, sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (hmc_no_own_gradient(h->likelihood)) {
+        std::vector<double> prm = h->like_params;
+        if (h->likelihood == SMCMC_LIKE_ASYM) {
+            if (prm.empty()) prm = {-1.0, 100.0};                                  // TAsymLogLikelihood.H:17-18
+            if (prm.size() != 2) return hfail(h, SMCMC_ERR_INVALID, "ASYM takes {positiveSlope, negativeSlope}");
+        } else if (h->likelihood == SMCMC_LIKE_CONSTRAINED) {
+            if ((int)prm.size() != 2 + 2 * D)
+                return hfail(h, SMCMC_ERR_INVALID,
+                             "CONSTRAINED needs {SummedValues, SummedConstraint, ExpectedValues[dim], PriorConstraints[dim]}");
+        } else if (prm.size() > hmc_like_doubles(D)) {
+            return hfail(h, SMCMC_ERR_INVALID, "a user likelihood takes at most dim^2 + 2 dim + 8 parameters");
+        }
+        if (!prm.empty())
+            HMC_TRY(h, hipMemcpyAsync(h->d_like, prm.data(), prm.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        HMC_TRY(h, hipStreamSynchronize(h->stream));
+    } else {
+        double b = 100.0;
+        if (h->likelihood == SMCMC_LIKE_ROSENBROCK && !h->like_params.empty()) b = h->like_params[0];
+        HMC_TRY(h, hipMemcpyAsync(h->d_like, &b, sizeof(double), hipMemcpyHostToDevice, h->stream));
+        HMC_TRY(h, hipStreamSynchronize(h->stream));
+    }
     std::vector<double> x(NP * D, 0.0);
     for (int d = 0; d < D; ++d)
         for (int c = 0; c < N; ++c) x[(size_t)d * NP + c] = broadcast ? x0[d] : x0[(size_t)d * N + c];
@@ -654,6 +680,9 @@ int smcmc_hmc_step(smcmc_hmc* h, int nsteps) {
     if (!h->started) return hfail(h, SMCMC_ERR_INVALID, "Must initialize starting point");   // :280-284
     if (nsteps <= 0) return SMCMC_OK;
     HMC_ON_DEVICE(h);
+    if (hmc_no_own_gradient(h->likelihood) && !hmc_generic_gradient(h))
+        return hfail(h, SMCMC_ERR_RUNTIME, "the likelihood has no gradient (TSimpleHMC.H:85-89: its functor returns false): "
+                                           "choose gradient type 2 (covariant), 3 (finite differences) or 5 (none)");
     if (hmc_generic_gradient(h)) {
         if (!h->exact) return hfail(h, SMCMC_ERR_UNSUPPORTED, "gradient types 2, 3 and 5 run in reference-order arithmetic only");
         int gst = hmc_generic_buffers(h);

@@ -272,6 +272,14 @@ __global__ void __launch_bounds__(W * kWave) hmc_step_kernel(const HmcParams p) 
                        prev_q = b;
                    }
                });
+        if constexpr (LIKE == SMCMC_LIKE_USER || LIKE == SMCMC_LIKE_ASYM || LIKE == SMCMC_LIKE_HORRIFIC ||
+                      LIKE == SMCMC_LIKE_CONSTRAINED) {
+            // a likelihood with no gradient of its own (the stress targets, a compiled-in user likelihood): one lane
+            // per chain walks the image of qn as the reference's functor walks its vector (the gather's last barrier
+            // has made every owner's part of qn visible); it is an HMC target through the finite-difference, the
+            // covariant or the zero gradient (TSimpleHMC.H:417-454, 508-529)
+            if (w == 0) lsum = serial_loglike<LIKE, true>(p.qn, chain, NP, D, p.like);
+        }
         if constexpr (LIKE == SMCMC_LIKE_QUADFORM) {
             // log L = -1/2 q^T Error q.  The gradient at the final position is still in gr[]
             // (gr = Error q): the potential is folded from it in dimension order instead of

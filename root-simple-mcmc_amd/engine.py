@@ -466,8 +466,9 @@ class HmcEngine:
     retuning (:665-858) is pooled over the ensemble every SetSyncInterval steps."""
 
     def __init__(self, dim, nchains=1, likelihood=LIKE_ISO_GAUSS, likelihood_params=None, seed=20240607,
-                 chain_offset=0, device=0, stream=None, exact=True):
-        self._lib = _capi.load()
+                 chain_offset=0, device=0, stream=None, exact=True, library=None):
+        # library: path of a build that carries a user likelihood (LIKE_USER as an HMC target through gradient type 2 / 3 / 5)
+        self._lib = _capi.load(library)
         self.dim, self.nchains = int(dim), int(nchains)
         h = C.c_void_p()
         st = self._lib.smcmc_hmc_create(self.dim, self.nchains, likelihood, seed, chain_offset, device, C.byref(h))

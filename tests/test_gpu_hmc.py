@@ -369,3 +369,23 @@ def test_hmc_sharded_exchange_equals_one_engine(gpu, oracle, kind, dim):
             assert np.array_equal(h.covariance, whole.covariance) and np.array_equal(h.average, whole.average)
             assert h.tuning == whole.tuning, f"step {step}: {h.tuning} != {whole.tuning}"
     assert whole.tuning["updates"] >= 1 and whole.lane("naccept").sum() > 0
+
+
+# ---------------------------------------------------------------- likelihoods without a gradient as HMC targets
+@pytest.mark.parametrize("kind,dim,gtype", [(4, 8, 3), (4, 70, 3), (6, 25, 3), (5, 12, 3), (4, 20, 5), (6, 25, 2)])
+def test_hmc_targets_without_a_gradient(gpu, oracle, kind, dim, gtype):
+    """The reference runs any operator()(Vector) under HMC through FiniteDifferenceGradient (TSimpleHMC.H:417-444), the
+    covariant gradient (:447-454) or none (:524-528); TAsymLogLikelihood, THorrificLogLikelihood and example4's
+    TConstrainedLikelihood have no gradient of their own (their functors throw / return false)."""
+    n = 64
+    prm = oracle.like_params(kind, dim)
+    e, o = _adaptive_pair(gpu, oracle, dim, n, kind, prm, True, 1)
+    x0 = {4: np.full(dim, 0.5), 5: np.full(dim, 0.01), 6: np.full(dim, 76.0)}[kind]
+    e.Start(x0); o.start(x0)
+    e.SetGradientType(gtype); o.set_gradient_type(gtype)
+    for k in range(2):
+        e.Step(3); o.step(3)
+        _same_hmc(e, o, f"block {k}")
+    with pytest.raises(gpu.SmcmcError) as err:
+        e.Step(1, gradient_type=0)                               # the functor has no gradient: the reference throws
+    assert err.value.status == 3

@@ -138,3 +138,30 @@ def test_cpp_host_with_a_user_likelihood(gpu, tmp_path):
     r = subprocess.run([exe, "512"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "(identical)" in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dim", [8, 100])
+def test_user_likelihood_as_an_hmc_target(gpu, dim):
+    """A compiled-in user likelihood under TSimpleHMC through the finite-difference gradient (TSimpleHMC.H:417-444):
+    examples/user_likelihood_asym.hip.h is the built-in TAsymLogLikelihood, chain for chain, bit for bit."""
+    n = 64
+    slopes = np.array([-1.0, 100.0])
+    user = gpu.HmcEngine(dim, n, likelihood=gpu.LIKE_USER, likelihood_params=slopes, seed=5, library=_user_lib(gpu))
+    ref = gpu.HmcEngine(dim, n, likelihood=gpu.LIKE_ASYM, likelihood_params=slopes, seed=5)
+    x0 = np.full(dim, 0.5)
+    for h in (user, ref):
+        h.Start(x0)
+        h.SetGradientType(3)
+    for k in range(2):
+        user.Step(3); ref.Step(3)
+        for a, b in zip(user.state(), ref.state()):
+            assert np.array_equal(a, b), f"block {k}"
+        for name in ("mean_epsilon", "leapfrog", "acceptance", "naccept"):
+            assert np.array_equal(user.lane(name), ref.lane(name)), name
+    assert user.lane("trials").max() == 6
+    with pytest.raises(gpu.SmcmcError):
+        user.Step(1, gradient_type=0)                            # no gradient of its own
+    with pytest.raises(gpu.SmcmcError) as err:
+        gpu.HmcEngine(dim, n, likelihood=gpu.LIKE_USER)          # the plain library carries no user likelihood
+    assert err.value.status == 5

@@ -34,7 +34,13 @@ CHAINS_PER_GPU = 65536
 WINDOW = 256                      # ensemble steps per launch / adaptation window
 HBM_PEAK_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E peak (spec)
 FP64_PEAK_TFLOPS = 78.6           # FP64 vector = FP64 matrix peak (they share one pipe)
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+def _latest_traffic_file():
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    return files[-1] if files else os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+
+
+TRAFFIC_FILE = _latest_traffic_file()   # the newest round's PMC summary (tools/profile_bench.sh + tools/summarize_pmc.py)
 
 
 def bytes_per_chain_step(dim):
@@ -418,7 +424,9 @@ def main():
                      "measured_hbm_GBps": (traffic / (kms * 1e-3) / 1e9) if traffic else None,
                      "fp64_TFLOPs": fp64_tflops, "fp64_issue_frac": fp64_tflops / FP64_PEAK_TFLOPS,
                      "fp64_model": "flops of SURVEY.md 8d (2 D^2 + 3 D) per chain-step / kernel time / 78.6 TFLOP/s",
-                     "limiter": "FP64 instruction issue (one wavefront per SIMD); see profiles/r02_notes.md",
+                     "measured_bound": "instruction issue: one wavefront per SIMD pays ~4 cycles per instruction of any kind and 64 per "
+                                       "FP64 matrix instruction, nothing overlaps them (profiles/r03_notes.md, tools/micro/pipe_overlap.hip)",
+                     "limiter": "instruction issue of a lone wavefront per SIMD; see profiles/r03_notes.md",
                      "algorithmic_bytes_per_launch": per_launch * bytes_cs,
                      "kernel": "step_kernel<%d,%s,%s,tri,moments>" % (dim, "QUADFORM" if args.header_tdummy else "ISO",
                                                                            "fused" if args.fast else "exact"),

@@ -1,6 +1,6 @@
 """Summaries of the rocprofv3 passes of tools/profile_bench.sh -> profiles/rNN_*.json / .csv.
 
-usage: python tools/summarize_pmc.py gpurun_out/r02 profiles/r02
+usage: python tools/summarize_pmc.py gpurun_out/r03 profiles/r03
 Picks the newest run directory of every pass; the first launch after Start is left out."""
 import csv
 import glob
@@ -19,12 +19,13 @@ def newest(pattern):
     return files[-1]
 
 
-def counters(path):
-    """{counter: [per-dispatch value]} for the headline kernel, in dispatch order"""
+def counters(path, kernel=None):
+    """{counter: [per-dispatch value]} for the headline kernel (or `kernel`), in dispatch order"""
+    kernel = kernel or KERNEL
     out = {}
     with open(path) as f:
         for row in csv.DictReader(f):
-            if KERNEL in row["Kernel_Name"]:
+            if kernel in row["Kernel_Name"]:
                 out.setdefault(row["Counter_Name"], {}).setdefault(int(row["Dispatch_Id"]), 0.0)
                 out[row["Counter_Name"]][int(row["Dispatch_Id"])] += float(row["Counter_Value"])
     return {k: [v[d] for d in sorted(v)][1:] for k, v in out.items()}
@@ -75,6 +76,33 @@ def main(src, dst):
                              "GRBM_GUI_ACTIVE summed over the 8 XCDs"},
               open(f"{dst}_pmc_sq.json", "w"), indent=1)
     print(json.dumps({"hbm_bytes_per_launch": 2 * fb + wb, **derived}, indent=1))
+    perchain(src, dst)
+
+
+def perchain(src, dst):
+    """SMCMC_MODE_PER_CHAIN: measured HBM bytes per chain-step of perchain_step_kernel against the algorithmic ones."""
+    pf, pw = glob.glob(f"{src}/pc_fetch/*/*_counter_collection.csv"), glob.glob(f"{src}/pc_write/*/*_counter_collection.csv")
+    if os.path.exists(f"{src}/perchain.json"):
+        shutil.copy(f"{src}/perchain.json", f"{dst}_perchain.json")
+    if not pf or not pw:
+        return
+    name = "perchain_step_kernel"
+    fetch = counters(sorted(pf, key=os.path.getmtime)[-1], name)["FETCH_SIZE"]
+    write = counters(sorted(pw, key=os.path.getmtime)[-1], name)["WRITE_SIZE"]
+    dim, chains, steps = 50, 65536, 16
+    fb, wb = 1024.0 * sum(fetch) / len(fetch), 1024.0 * sum(write) / len(write)
+    alg = 8 * 3 * dim * (dim + 1) // 2 + 8 * 7 * dim + 16
+    out = {"kernel": "smcmc::perchain_step_kernel<0>", "workload": f"D={dim}, {chains} chains, {steps} steps per launch",
+           "raw": {"FETCH_SIZE_KB_per_launch": fetch, "WRITE_SIZE_KB_per_launch": write},
+           "fetch_bytes_corrected": 2 * fb, "write_bytes": wb,
+           "hbm_bytes_per_chain_step": (2 * fb + wb) / (chains * steps), "algorithmic_bytes_per_chain_step": alg,
+           "read_bytes_per_chain_step": 2 * fb / (chains * steps), "write_bytes_per_chain_step": wb / (chains * steps),
+           "algorithmic_read": 8 * 2 * dim * (dim + 1) // 2 + 8 * 5 * dim + 8, "algorithmic_write": 8 * dim * (dim + 1) // 2 + 8 * 2 * dim + 8,
+           "correction": "FETCH_SIZE doubled (gfx950: 128-B requests counted at 64 B), as for the headline kernel",
+           "collection": "separate rocprofv3 --pmc passes of tools/perchain_time.py --chains 65536 --steps 16 --launches 2; the "
+                         "first launch (8 warm-up steps) left out"}
+    json.dump(out, open(f"{dst}_perchain_traffic.json", "w"), indent=1)
+    print(json.dumps({k: out[k] for k in ("hbm_bytes_per_chain_step", "algorithmic_bytes_per_chain_step")}, indent=1))
 
 
 if __name__ == "__main__":

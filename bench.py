@@ -215,14 +215,17 @@ def hmc_ess_per_trajectory(h, nsteps=48):
     return 1.0 / float(tau.max())
 
 
-def extra_hmc(pkg, torch, stream, dim, chains, leapfrog, exact, steps, tuned, burn=2, eps0=None, ess=False):
+def extra_hmc(pkg, torch, stream, dim, chains, leapfrog, exact, steps, tuned, burn=2, eps0=None, ess=False, diagonal=False):
     """Config 5: TSimpleHMC, header-form TDummyLogLikelihood with its analytic gradient, start at 1 (SimpleHMC.C:45),
     SetLeapFrog(20).  tuned: the step length is left to the chain (the covariance fold and the pooled UpdateErrorMatrix run
     every step, inside the timed region) -- from the reference's start value 0.05 (TSimpleHMC.H:229: 25 times the
     stability limit of this target, every trajectory is rejected and the step length never moves), or, with eps0, from
     SetMeanEpsilon(eps0 > 0), a start the target can take; otherwise SetMeanEpsilon(< 0) fixes it.  `burn` untimed
     steps first; accept_rate is the acceptance inside the timed region."""
-    h = pkg.HmcEngine(dim, chains, likelihood=pkg.LIKE_QUADFORM, likelihood_params=tdummy_error(dim), seed=20240607,
+    # diagonal: a quadratic form the reference's own tuning can handle (variances 0.25 .. 4) next to the header form, whose
+    # rho = 0.999999 pair needs epsilon < 0.002 while UpdateErrorMatrix never sets less than 0.5 * 0.01 (TSimpleHMC.H:825-839)
+    error = np.diag(1.0 / np.linspace(0.25, 4.0, dim)) if diagonal else tdummy_error(dim)
+    h = pkg.HmcEngine(dim, chains, likelihood=pkg.LIKE_QUADFORM, likelihood_params=error, seed=20240607,
                       exact=exact, stream=stream.cuda_stream)
     h.Start(np.ones(dim))
     if not tuned:
@@ -246,8 +249,9 @@ def extra_hmc(pkg, torch, stream, dim, chains, leapfrog, exact, steps, tuned, bu
     flops = (leapfrog + 1) * 2 * dim * dim + 3 * dim * dim + dim * dim
     acc1, tr1 = h.lane("naccept").astype(np.float64).sum(), h.lane("trials").astype(np.float64).sum()
     eps = h.lane("mean_epsilon")
-    out = {"workload": "TSimpleHMC header-form TDummy D=%d, %d chains x %d leapfrog steps, %s step length" %
-                       (dim, chains, leapfrog, ("self-tuned from SetMeanEpsilon(%g)" % eps0 if eps0 is not None else
+    out = {"workload": "TSimpleHMC %s D=%d, %d chains x %d leapfrog steps, %s step length" %
+                       ("quadratic form with variances 0.25..4" if diagonal else "header-form TDummy", dim, chains, leapfrog,
+                        ("self-tuned from SetMeanEpsilon(%g)" % eps0 if eps0 is not None else
                                                 "self-tuned from the reference's start value") if tuned else "fixed"),
            "trajectories_per_s": rate, "ms_per_step": dt / steps * 1e3, "device_ms_per_step": e0.elapsed_time(e1) / steps,
            "steps": steps, "burn_in_steps": burn, "arithmetic": "reference-order" if exact else "fused (matrix pipe)",
@@ -465,8 +469,8 @@ def main():
             extra["c5_hmc_d500_8192_L20"] = extra_hmc(pkg, torch, stream, 500, 8192, 20, True, 3, True)
             extra["c5_hmc_d500_8192_L20_fused"] = extra_hmc(pkg, torch, stream, 500, 8192, 20, False, 10, True)
             # the sampler rows: a burn-in in which the chains accept, then 200 trajectories timed
-            extra["c5_hmc_d500_8192_L20_tuned_sampler_fused"] = extra_hmc(pkg, torch, stream, 500, 8192, 20, False, 200, True,
-                                                                          burn=300, eps0=0.0005, ess=True)
+            extra["c5_hmc_d500_8192_L20_tuned_sampler_diag_target_fused"] = extra_hmc(
+                pkg, torch, stream, 500, 8192, 20, False, 200, True, burn=300, ess=True, diagonal=True)
             extra["c5_hmc_d500_8192_L20_fixed_step_fused"] = extra_hmc(pkg, torch, stream, 500, 8192, 20, False, 200, False,
                                                                        burn=100, ess=True)
         except Exception as exc:   # never a reason to lose the headline

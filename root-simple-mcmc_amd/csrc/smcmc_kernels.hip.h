@@ -197,6 +197,31 @@ __device__ __forceinline__ void piece_ready(f64x2 (&q)[kPiece / 2]) {
     else asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(q[0]) : "n"(N));
 }
 
+// The matrix-pipe operands of one k-quad (four chains) of the moment fold, fetched one k-quad ahead: T raw values of the
+// accepted point per lane (plus the strip's), inline assembly like the piece reads -- issued in the middle of a piece,
+// covered by the next piece's piece_ready, consumed pieces later (operands_ready ties them behind that wait).  Read and
+// used on the spot they cost the LDS latency sixteen times per step.
+template <int T, int KK, int t = 0>
+__device__ __forceinline__ void fetch_operands(const uint32_t (&xaddr)[T], double (&raw)[T]) {
+    if constexpr (t < T) {
+        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(raw[t]) : "v"(xaddr[t]), "n"(32 * KK));
+        fetch_operands<T, KK, t + 1>(xaddr, raw);
+    }
+}
+template <int KK>
+__device__ __forceinline__ void fetch_operand(uint32_t addr, double& raw) {
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(raw) : "v"(addr), "n"(32 * KK));
+}
+template <int T, int t = 0>
+__device__ __forceinline__ void operands_ready(double (&raw)[T], double& raws) {
+    if constexpr (t < T) {
+        asm volatile("" : "+v"(raw[t]));
+        operands_ready<T, t + 1>(raw, raws);
+    } else {
+        asm volatile("" : "+v"(raws));
+    }
+}
+
 // row ti of lower-triangular tile number `tile` (tile = ti (ti + 1) / 2 + tj, tj <= ti)
 constexpr int tile_row(int tile) {
     int ti = 0;
@@ -474,6 +499,16 @@ __global__ void __launch_bounds__(kWave, 2) step_kernel(const StepParams p) {
     }
     __syncthreads();
 
+    // operand prefetch of the fold (fetch_operands): only where a k-quad's matrix instructions span several pieces
+    constexpr bool OPF = MOMENTS && NT >= 3;
+    double raw[OPF ? T : 1], raws = 0.0;
+    uint32_t xaddr[OPF ? T : 1], xsaddr = 0;
+    if constexpr (OPF) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) xaddr[t] = (uint32_t)(uintptr_t)(lds_cptr_f64)(xs + xrow[t]);
+        if constexpr (STRIP) xsaddr = (uint32_t)(uintptr_t)(lds_cptr_f64)(xs + xsrow);
+    }
+
     double xp[DP];
     const uint32_t aw = smcmc_accept_word((uint32_t)D);
 
@@ -628,6 +663,10 @@ __global__ void __launch_bounds__(kWave, 2) step_kernel(const StepParams p) {
         last_x0 = x0;
 
         // ---- B: proposal (TSimpleMCMC.H:709-724) ----
+        if constexpr (OPF) {
+            fetch_operands<T, 0>(xaddr, raw);
+            if constexpr (STRIP) fetch_operand<0>(xsaddr, raws);
+        }
 #pragma unroll
         for (int d = 0; d < DP; ++d) xp[d] = xcol[d * kXStride];
         uint32_t uword = 0;
@@ -705,14 +744,23 @@ __global__ void __launch_bounds__(kWave, 2) step_kernel(const StepParams p) {
                         constexpr int m = m_lo + decltype(mc)::value;
                         constexpr int kk = m / NT, tile = m % NT;
                         if constexpr (tile == 0) {
+                            if constexpr (OPF) operands_ready<T>(raw, raws);   // fetched a k-quad ago, a piece_ready since
 #pragma unroll
                             for (int t = 0; t < T; ++t) {
-                                ma[t] = xs[xrow[t] + 4 * kk] - c0r[t];
+                                if constexpr (OPF) ma[t] = raw[t] - c0r[t];
+                                else ma[t] = xs[xrow[t] + 4 * kk] - c0r[t];
                                 if (16 * t + 15 > DP) ma[t] = (16 * t + (lane & 15) <= DP) ? ma[t] : 0.0;   // rows past the ones row
                             }
                             if constexpr (STRIP) {
-                                ms = xs[xsrow + 4 * kk] - c0s;
+                                if constexpr (OPF) ms = raws - c0s;
+                                else ms = xs[xsrow + 4 * kk] - c0s;
                                 ms = (16 * Geo<DP>::T16 + (lane & 3) <= DP) ? ms : 0.0;
+                            }
+                            if constexpr (OPF && kk + 1 < 16) {
+                                // the next k-quad's first matrix instruction sits in a later piece
+                                static_assert(((long)(kk + 1) * NT * G) / NM > g, "operand prefetch needs a piece boundary");
+                                fetch_operands<T, kk + 1>(xaddr, raw);
+                                if constexpr (STRIP) fetch_operand<kk + 1>(xsaddr, raws);
                             }
                         }
                         if constexpr (!STRIP || tile < NT16) {

@@ -630,14 +630,16 @@ bool per_chain(const smcmc_engine* h) { return h->mode == SMCMC_MODE_PER_CHAIN; 
 int pc_alloc(smcmc_engine* h) {
     if (h->d_pc_cov) return SMCMC_OK;
     const size_t NP = (size_t)h->npad, D = (size_t)h->dim, npk = D * (D + 1) / 2;
-    HIP_TRY(h, hipMalloc(&h->d_pc_cov, sizeof(double) * npk * NP));
-    HIP_TRY(h, hipMalloc(&h->d_pc_ut, sizeof(double) * D * D * NP));
+    // the kernel reads both streams in whole chunks and primes its buffers unconditionally: padding behind the last tile
+    const size_t pad = (size_t)smcmc::kPcPad * smcmc::kWave;
+    HIP_TRY(h, hipMalloc(&h->d_pc_cov, sizeof(double) * (npk * NP + pad)));
+    HIP_TRY(h, hipMalloc(&h->d_pc_ut, sizeof(double) * (D * D * NP + pad)));
     HIP_TRY(h, hipMalloc(&h->d_pc_centre, sizeof(double) * D * NP));
     HIP_TRY(h, hipMalloc(&h->d_pc_last, sizeof(double) * D * NP));
     HIP_TRY(h, hipMalloc(&h->d_pc_tmpl, sizeof(double) * (npk + D * D + D)));
     HIP_TRY(h, hipMalloc(&h->d_pc_flag, sizeof(int)));
-    HIP_TRY(h, hipMemset(h->d_pc_cov, 0, sizeof(double) * npk * NP));
-    HIP_TRY(h, hipMemset(h->d_pc_ut, 0, sizeof(double) * D * D * NP));
+    HIP_TRY(h, hipMemset(h->d_pc_cov, 0, sizeof(double) * (npk * NP + pad)));
+    HIP_TRY(h, hipMemset(h->d_pc_ut, 0, sizeof(double) * (D * D * NP + pad)));
     HIP_TRY(h, hipMemset(h->d_pc_centre, 0, sizeof(double) * D * NP));
     HIP_TRY(h, hipMemset(h->d_pc_last, 0, sizeof(double) * D * NP));
     HIP_TRY(h, hipMemset(h->d_pc_flag, 0, sizeof(int)));
@@ -715,6 +717,15 @@ template <typename T>
 hipError_t pc_put_column(T* base, size_t npad, int chain, int rows, const T* in) {
     return hipMemcpy2D(base + chain, npad * sizeof(T), in, sizeof(T), sizeof(T), (size_t)rows, hipMemcpyHostToDevice);
 }
+// one chain's elements of a wavefront-tiled image (pc_tile_index): `count` of the `rows` elements of the tile
+inline hipError_t pc_get_tiled(const double* base, int chain, int rows, int count, double* out) {
+    return hipMemcpy2D(out, sizeof(double), base + smcmc::pc_tile_index(0, (size_t)chain, rows), smcmc::kWave * sizeof(double),
+                       sizeof(double), (size_t)count, hipMemcpyDeviceToHost);
+}
+inline hipError_t pc_put_tiled(double* base, int chain, int rows, int count, const double* in) {
+    return hipMemcpy2D(base + smcmc::pc_tile_index(0, (size_t)chain, rows), smcmc::kWave * sizeof(double), in, sizeof(double),
+                       sizeof(double), (size_t)count, hipMemcpyHostToDevice);
+}
 
 // The chains the latest launch stopped (a Cholesky pivot failed inside their UpdateProposal, or their covariance has
 // no trace): the fallback ladder of TSimpleMCMC.H:1134-1389 on the host, chain by chain, exactly where
@@ -734,7 +745,7 @@ int pc_host_ladder(smcmc_engine* h, bool explicit_update) {
         SharedProposal T(*h->prop);                      // the settings; the state comes from the chain
         HIP_TRY(h, pc_get_column(h->d_lane_f64, NP, c, SMCMC_LANE_F64_COUNT_, lf.data()));
         HIP_TRY(h, pc_get_column(h->d_lane_i32, NP, c, SMCMC_LANE_I32_COUNT_, li.data()));
-        HIP_TRY(h, pc_get_column(h->d_pc_cov, NP, c, npk, packed.data()));
+        HIP_TRY(h, pc_get_tiled(h->d_pc_cov, c, npk, npk, packed.data()));
         HIP_TRY(h, pc_get_column(h->d_pc_centre, NP, c, D, T.centre.data()));
         HIP_TRY(h, pc_get_column(h->d_pc_last, NP, c, D, T.lastPoint.data()));
         for (int i = 0; i < D; ++i)
@@ -750,8 +761,8 @@ int pc_host_ladder(smcmc_engine* h, bool explicit_update) {
         for (int i = 0; i < D; ++i)
             for (int j = 0; j <= i; ++j) packed[(size_t)i * (i + 1) / 2 + j] = T.cov[(size_t)i * D + j];
         pc_pack_decomp(T, ut);
-        HIP_TRY(h, pc_put_column(h->d_pc_cov, NP, c, npk, packed.data()));
-        HIP_TRY(h, pc_put_column(h->d_pc_ut, NP, c, D * D, ut.data()));
+        HIP_TRY(h, pc_put_tiled(h->d_pc_cov, c, npk, npk, packed.data()));
+        HIP_TRY(h, pc_put_tiled(h->d_pc_ut, c, D * D, D * D, ut.data()));
         HIP_TRY(h, pc_put_column(h->d_pc_centre, NP, c, D, T.centre.data()));
         lf[SMCMC_LANE_CENTER_TRIALS] = T.centreTrials; lf[SMCMC_LANE_COVARIANCE_TRIALS] = T.covTrials;
         lf[SMCMC_LANE_SIGMA] = T.sigma; lf[SMCMC_LANE_SIGMA_TRACE] = T.sigmaTrace;
@@ -1890,7 +1901,7 @@ int smcmc_read_chain_proposal(smcmc_engine* h, int chain, double* centre, double
     if (centre) HIP_TRY(h, pc_get_column(h->d_pc_centre, NP, chain, D, centre));
     if (covariance) {
         std::vector<double> packed(npk);
-        HIP_TRY(h, pc_get_column(h->d_pc_cov, NP, chain, npk, packed.data()));
+        HIP_TRY(h, pc_get_tiled(h->d_pc_cov, chain, npk, npk, packed.data()));
         for (int i = 0; i < D; ++i)
             for (int j = 0; j <= i; ++j)
                 covariance[(size_t)i * D + j] = covariance[(size_t)j * D + i] = packed[(size_t)i * (i + 1) / 2 + j];
@@ -1898,7 +1909,7 @@ int smcmc_read_chain_proposal(smcmc_engine* h, int chain, double* centre, double
     if (decomposition) {
         std::vector<double> ut((size_t)D * D);
         int32_t full = 0;
-        HIP_TRY(h, pc_get_column(h->d_pc_ut, NP, chain, D * D, ut.data()));
+        HIP_TRY(h, pc_get_tiled(h->d_pc_ut, chain, D * D, D * D, ut.data()));
         HIP_TRY(h, hipMemcpy(&full, h->d_lane_i32 + (size_t)SMCMC_LANE_DECOMP_FULL * NP + chain, sizeof(int32_t), hipMemcpyDeviceToHost));
         std::fill(decomposition, decomposition + (size_t)D * D, 0.0);
         for (int j = 0; j < D; ++j)
@@ -1911,11 +1922,12 @@ int smcmc_read_chain_proposal(smcmc_engine* h, int chain, double* centre, double
 }
 
 // SMCMC_MODE_PER_CHAIN: a [rows] vector handed to every chain's column
-static int pc_broadcast_rows(smcmc_engine* h, double* dst, const double* values, int rows) {
+static int pc_broadcast_rows(smcmc_engine* h, double* dst, const double* values, int rows, bool tiled) {
     const size_t NP = (size_t)h->npad;
     std::vector<double> img((size_t)rows * NP, 0.0);
     for (int r = 0; r < rows; ++r)
-        for (int c = 0; c < h->nchains; ++c) img[(size_t)r * NP + c] = values[r];
+        for (int c = 0; c < h->nchains; ++c)
+            img[tiled ? smcmc::pc_tile_index(r, (size_t)c, rows) : (size_t)r * NP + c] = values[r];
     HIP_TRY(h, hipMemcpyAsync(dst, img.data(), img.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return SMCMC_OK;
@@ -1935,7 +1947,7 @@ int smcmc_set_center(smcmc_engine* h, const double* in) {
     ON_DEVICE(h);
     { int sst_ = sync_shared_to_host(h, true); if (sst_) return sst_; }
     std::copy(in, in + h->dim, h->prop->centre.begin());
-    if (per_chain(h) && h->started) return pc_broadcast_rows(h, h->d_pc_centre, in, h->dim);
+    if (per_chain(h) && h->started) return pc_broadcast_rows(h, h->d_pc_centre, in, h->dim, false);
     return h->started ? upload_shared(h) : SMCMC_OK;
 }
 
@@ -1958,7 +1970,7 @@ int smcmc_set_covariance(smcmc_engine* h, const double* in) {
         std::vector<double> packed((size_t)D * (D + 1) / 2);
         for (int i = 0; i < D; ++i)
             for (int j = 0; j <= i; ++j) packed[(size_t)i * (i + 1) / 2 + j] = in[(size_t)i * D + j];
-        return pc_broadcast_rows(h, h->d_pc_cov, packed.data(), (int)packed.size());
+        return pc_broadcast_rows(h, h->d_pc_cov, packed.data(), (int)packed.size(), true);
     }
     return SMCMC_OK;
 }

@@ -35,9 +35,9 @@ __global__ void perchain_broadcast_kernel(const PerChainBroadcast p) {
     const size_t NP = (size_t)p.npad;
     double* lf = p.lane_f64 + chain;
     int32_t* li = p.lane_i32 + chain;
-    for (int k = 0; k < npk; ++k) p.cov[(size_t)k * NP + chain] = p.cov_packed[k];
+    for (int k = 0; k < npk; ++k) p.cov[pc_tile_index(k, (size_t)chain, npk)] = p.cov_packed[k];
     const int nu = p.decomp_full ? D * D : npk;
-    for (int k = 0; k < nu; ++k) p.ut_out[(size_t)k * NP + chain] = p.ut[k];
+    for (int k = 0; k < nu; ++k) p.ut_out[pc_tile_index(k, (size_t)chain, D * D)] = p.ut[k];
     li[SMCMC_LANE_DECOMP_FULL * NP] = p.decomp_full;
     li[SMCMC_LANE_LAST_UPDATE_PATH * NP] = p.last_path;
     li[SMCMC_LANE_UPDATE_STATUS * NP] = kPcOk;

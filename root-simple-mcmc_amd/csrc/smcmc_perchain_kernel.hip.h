@@ -26,6 +26,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "smcmc.h"
 #include "smcmc_detmath.h"
@@ -34,7 +35,13 @@
 
 namespace smcmc {
 
-constexpr int kPcBlock = 32;          // elements of a stream per block (loads in flight per lane)
+constexpr int kPcChunk = 8;           // elements of a stream per chunk (one address register, immediate offsets)
+constexpr int kPcDepth = 5;           // chunk buffers in rotation: the loads of kPcDepth - 1 chunks (32 per lane) are in
+                                      // flight behind the chunk being consumed.  The streams are read in whole chunks
+                                      // and primed unconditionally: both images carry kPcPad elements of padding behind
+                                      // the last tile (whose first 64 doubles also take the stores of idle lanes).
+constexpr int kPcPad = kPcDepth * kPcChunk + kPcChunk * (kPcChunk + 1) / 2;
+constexpr int kPcBatch = 8;           // loads issued together in the O(D) loops over the [dim][chain] images
 constexpr int kPcMaxDim = 63;         // one lane per column in the wavefront's Cholesky
 constexpr int kPcRPitch = 65;         // row pitch of the LDS matrix of the Cholesky
 
@@ -62,8 +69,9 @@ struct PerChainParams {
     double* proposed;          // [dim][npad] the proposal (fProposed), also the image the likelihood walks
     double* last_point;        // [dim][npad] fLastPoint
     double* centre;            // [dim][npad] fCentralPoint
-    double* cov;               // [dim (dim + 1) / 2][npad] fCurrentCov, lower triangle, row major: k = i (i + 1) / 2 + j, j <= i
-    double* ut;                // [dim * dim][npad] fDecomposition: kk = j (j + 1) / 2 + i holds U(i, j), i <= j (column
+    double* cov;               // fCurrentCov, lower triangle, row major: k = i (i + 1) / 2 + j, j <= i; wavefront tiles
+                               // [npad / 64][dim (dim + 1) / 2][64] (pc_tile_index)
+    double* ut;                // fDecomposition, wavefront tiles [npad / 64][dim * dim][64]: kk = j (j + 1) / 2 + i holds U(i, j), i <= j (column
                                // packed: a proposal column walks it contiguously); a full matrix (eigen rung of the
                                // ladder, SMCMC_LANE_DECOMP_FULL) keeps U(i, j), j < i, at dim (dim + 1) / 2 + i (i - 1) / 2 + j
     double* lane_f64;
@@ -73,6 +81,14 @@ struct PerChainParams {
     int save_stride;
     int* flag_count;           // += 1 for every chain that stopped for the host
 };
+
+// Layout of the two O(D^2) images: wavefront tiles [chain / 64][k][chain % 64].  A wavefront's element k is one
+// 512-byte line and its whole stream one contiguous run of `rows` such lines: sequential pages for the address
+// translation and open rows for HBM (a [k][chain] image over all chains puts consecutive k of a wavefront
+// npad * 8 bytes apart -- a new page for every load).
+__host__ __device__ inline size_t pc_tile_index(int k, size_t chain, int rows) {
+    return ((chain >> 6) * (size_t)rows + (size_t)k) * kWave + (chain & (kWave - 1));
+}
 
 // (row, column) of packed index k = i (i + 1) / 2 + j, j <= i
 __device__ __forceinline__ void pc_unpack(int k, int& i, int& j) {
@@ -96,6 +112,11 @@ __global__ void __launch_bounds__(kWave, 1) perchain_step_kernel(const PerChainP
     const size_t NP = (size_t)p.npad;
     const uint32_t gid = p.chain_offset + (uint32_t)chain;
     double* const vec = lds + lane;
+    double* const gcov = p.cov + (size_t)group * npk * kWave;        // the wavefront's tiles (pc_tile_index)
+    double* const gut = p.ut + (size_t)group * D * D * kWave;
+    double* const ccov = gcov + lane;
+    double* const cut = gut + lane;
+    double* const gut_pad = p.ut + (size_t)D * D * NP + lane;       // the padding behind the last tile
 
     double* lf = p.lane_f64 + chain;
     int32_t* li = p.lane_i32 + chain;
@@ -160,12 +181,11 @@ __global__ void __launch_bounds__(kWave, 1) perchain_step_kernel(const PerChainP
         while (todo != 0) {
             const int L = __builtin_ctzll(todo);
             todo &= todo - 1;
-            const size_t cl = (size_t)group * kWave + (size_t)L;
             __syncthreads();
             for (int k = lane; k < npk; k += kWave) {
                 int i, j;
                 pc_unpack(k, i, j);
-                const double v = p.cov[(size_t)k * NP + cl];
+                const double v = gcov[(size_t)k * kWave + L];
                 lds[i * kPcRPitch + j] = v;
                 lds[j * kPcRPitch + i] = v;
             }
@@ -193,7 +213,7 @@ __global__ void __launch_bounds__(kWave, 1) perchain_step_kernel(const PerChainP
                 for (int kk = lane; kk < npk; kk += kWave) {
                     int j, i;
                     pc_unpack(kk, j, i);                               // kk = j (j + 1) / 2 + i, i <= j
-                    p.ut[(size_t)kk * NP + cl] = lds[i * kPcRPitch + j];
+                    gut[(size_t)kk * kWave + L] = lds[i * kPcRPitch + j];
                 }
             }
             if (lane == L) {
@@ -208,7 +228,7 @@ __global__ void __launch_bounds__(kWave, 1) perchain_step_kernel(const PerChainP
     // trace of the lane's covariance, summed in index order (GetCovarianceTrace :961-967)
     auto load_trace = [&]() {
         double t = 0.0;
-        for (int i = 0; i < D; ++i) t += p.cov[(size_t)(i * (i + 1) / 2 + i) * NP + chain];
+        for (int i = 0; i < D; ++i) t += ccov[(size_t)(i * (i + 1) / 2 + i) * kWave];
         return t;
     };
 
@@ -250,50 +270,93 @@ __global__ void __launch_bounds__(kWave, 1) perchain_step_kernel(const PerChainP
                 }
                 // ---- running centre (:1780-1788); the diffs x - c stay in LDS for the covariance ----
                 __syncthreads();
-                for (int i = 0; i < D; ++i) {
-                    const double xi = p.x[(size_t)i * NP + chain];
-                    double c = p.centre[(size_t)i * NP + chain];
-                    c *= centre_trials;
-                    c += xi;
-                    c /= centre_trials + 1;
-                    if (upd) p.centre[(size_t)i * NP + chain] = c;
-                    vec[i * kWave] = xi - c;
+                for (int i0 = 0; i0 < D; i0 += kPcBatch) {
+                    double xv[kPcBatch], cv[kPcBatch];
+#pragma unroll
+                    for (int q = 0; q < kPcBatch; ++q) {
+                        const int i = (i0 + q < D) ? i0 + q : D - 1;
+                        xv[q] = p.x[(size_t)i * NP + chain];
+                        cv[q] = p.centre[(size_t)i * NP + chain];
+                    }
+#pragma unroll
+                    for (int q = 0; q < kPcBatch; ++q) {
+                        if (i0 + q < D) {
+                            double c = cv[q];
+                            c *= centre_trials;
+                            c += xv[q];
+                            c /= centre_trials + 1;
+                            if (upd) p.centre[(size_t)(i0 + q) * NP + chain] = c;
+                            vec[(i0 + q) * kWave] = xv[q] - c;
+                        }
+                    }
                 }
                 if (upd) centre_trials = dmin(p.cov_window, centre_trials + 1.0);
                 // ---- running covariance (:1795-1820): the stream ----
                 double trace = 0.0;
                 if (!p.cov_frozen) {
-                    double cur[kPcBlock], nxt[kPcBlock];
+                    // Chunks of kPcChunk consecutive elements through kPcDepth rotating buffers.  The steady loop has
+                    // no conditional memory operation (a lane outside `upd` stores back what it loaded): the waits
+                    // the compiler counts out are then exact, and the loads of kPcDepth - 1 chunks stay in flight
+                    // behind the chunk whose divisions -- independent chains -- are being worked off.  The
+                    // (row, column) of every element is wavefront-uniform bookkeeping.
+                    constexpr int CH = kPcChunk;
+                    double buf[kPcDepth][CH];
                     const double tv = cov_trials, tv1 = cov_trials + 1.0;
+                    const int nch = (npk + CH - 1) / CH;
+                    auto fetch = [&](double (&b)[CH], int c) {
+                        const double* src = ccov + (size_t)c * (CH * kWave);
 #pragma unroll
-                    for (int q = 0; q < kPcBlock; ++q)
-                        if (q < npk) nxt[q] = __builtin_nontemporal_load(&p.cov[(size_t)q * NP + chain]);
-                    int i = 0, j = 0;
-                    double di = vec[0];
-                    for (int k0 = 0; k0 < npk; k0 += kPcBlock) {
+                        for (int q = 0; q < CH; ++q) b[q] = __builtin_nontemporal_load(src + q * kWave);
+                    };
+                    int ci = 0, cj = 0;
+                    auto consume = [&](double (&b)[CH], int c, auto whole) {
+                        constexpr bool WHOLE = decltype(whole)::value;      // every element of the chunk exists
+                        const int k0 = c * CH;
+                        double* dst = ccov + (size_t)k0 * kWave;
+                        double da[CH], db[CH], v[CH];
+                        bool dg[CH];
 #pragma unroll
-                        for (int q = 0; q < kPcBlock; ++q) cur[q] = nxt[q];
-                        const int k1 = k0 + kPcBlock;
+                        for (int q = 0; q < CH; ++q) {
+                            da[q] = vec[(ci < D ? ci : 0) * kWave];
+                            db[q] = vec[(cj < D ? cj : 0) * kWave];
+                            dg[q] = cj == ci;
+                            cj = dg[q] ? 0 : cj + 1;
+                            ci = dg[q] ? ci + 1 : ci;
+                        }
 #pragma unroll
-                        for (int q = 0; q < kPcBlock; ++q)
-                            if (k1 + q < npk) nxt[q] = __builtin_nontemporal_load(&p.cov[(size_t)(k1 + q) * NP + chain]);
+                        for (int q = 0; q < CH; ++q) {
+                            double t = b[q];
+                            const double r = da[q] * db[q];
+                            t *= tv;
+                            t += r;
+                            t /= tv1;
+                            v[q] = t;
+                        }
 #pragma unroll
-                        for (int q = 0; q < kPcBlock; ++q) {
-                            if (k0 + q < npk) {
-                                double v = cur[q];
-                                const double r = di * vec[j * kWave];
-                                v *= tv;
-                                v += r;
-                                v /= tv1;
-                                if (upd) __builtin_nontemporal_store(v, &p.cov[(size_t)(k0 + q) * NP + chain]);
-                                if (j == i) {
-                                    trace += v;
-                                    ++i;
-                                    j = 0;
-                                    di = vec[(i < D ? i : 0) * kWave];
-                                } else {
-                                    ++j;
-                                }
+                        for (int q = 0; q < CH; ++q) {
+                            if (WHOLE || k0 + q < npk) {
+                                __builtin_nontemporal_store(upd ? v[q] : b[q], dst + q * kWave);
+                                trace = dg[q] ? trace + v[q] : trace;
+                            }
+                        }
+                    };
+#pragma unroll
+                    for (int sl = 0; sl < kPcDepth; ++sl) fetch(buf[sl], sl);
+                    int c0 = 0;
+                    for (; c0 + 2 * kPcDepth <= nch; c0 += kPcDepth) {
+#pragma unroll
+                        for (int sl = 0; sl < kPcDepth; ++sl) {
+                            consume(buf[sl], c0 + sl, std::true_type{});
+                            fetch(buf[sl], c0 + sl + kPcDepth);
+                        }
+                    }
+                    for (; c0 < nch; c0 += kPcDepth) {
+#pragma unroll
+                        for (int sl = 0; sl < kPcDepth; ++sl) {
+                            const int c = c0 + sl;
+                            if (c < nch) {
+                                consume(buf[sl], c, std::false_type{});
+                                if (c + kPcDepth < nch) fetch(buf[sl], c + kPcDepth);
                             }
                         }
                     }
@@ -311,12 +374,24 @@ __global__ void __launch_bounds__(kWave, 1) perchain_step_kernel(const PerChainP
             if (live && !forced_now) {                                 // :1829-1830
                 last_value = logl;
                 last_x0 = x0;
-                for (int i = 0; i < D; ++i) p.last_point[(size_t)i * NP + chain] = p.x[(size_t)i * NP + chain];
+                for (int i0 = 0; i0 < D; i0 += kPcBatch) {
+                    double xv[kPcBatch];
+#pragma unroll
+                    for (int q = 0; q < kPcBatch; ++q) xv[q] = p.x[(size_t)((i0 + q < D) ? i0 + q : D - 1) * NP + chain];
+#pragma unroll
+                    for (int q = 0; q < kPcBatch; ++q)
+                        if (i0 + q < D) p.last_point[(size_t)(i0 + q) * NP + chain] = xv[q];
+                }
             }
             resume = false;
 
             // ---- the proposal (:709-724) into its image ----
             uint32_t uword = 0;
+            // the trial step's square sum (:391-396) and -- ISO_GAUSS -- the likelihood are taken at the column ends of
+            // the proposal stream, in the reference's index order, instead of in passes over the images: only when
+            // no lane of the wavefront has a full decomposition or a forced step
+            const bool fused = !__any(ufull != 0) && !__any(forced_now);
+            double sqr = 0.0, lsum = 0.0;
             if (forced_now) {
                 for (int i = 0; i < D; ++i)
                     if (live) p.proposed[(size_t)i * NP + chain] = p.forced[(size_t)i * NP + chain];
@@ -339,34 +414,112 @@ __global__ void __launch_bounds__(kWave, 1) perchain_step_kernel(const PerChainP
                     const smcmc_u32x4 blk = smcmc_draw_block(p.seed, gid, step, aw >> 2, SMCMC_STREAM_STEP);
                     uword = smcmc_select_word(blk, aw & 3u);
                 }
-                // column j: x'[j] = x[j] + sum_{i <= j} (sigma r_i) U(i, j), i ascending, un-fused
-                double cur[kPcBlock], nxt[kPcBlock];
+                // column j: x'[j] = x[j] + sum_{i <= j} (sigma r_i) U(i, j), i ascending, un-fused; the columns lie one
+                // behind the other in the stream.
+                double acc = x0, xcur = x0;
+                auto close_column = [&](double xnext) {                // everything of a column's end but the store
+                    if (fused) {
+                        const double ts = acc - xcur;
+                        sqr += ts * ts;
+                        if constexpr (LIKE == SMCMC_LIKE_ISO_GAUSS) {
+                            const double th = -0.5 * acc;
+                            lsum += th * acc;
+                        }
+                    }
+                    acc = xnext;
+                    xcur = xnext;
+                };
+                // a lane that is not running leaves its proposal alone: its stores go to the padding of the image
+                double* const pdst = live ? p.proposed + chain : gut_pad;
+                const size_t pstride = live ? NP : 0;
+                // the first columns (shorter than a chunk): their 36 elements and start values loaded up front
+                constexpr int CH = kPcChunk;
+                constexpr int PRE = CH * (CH + 1) / 2;
+                const int P = D < CH ? D : CH;
+                const int kP = P * (P + 1) / 2;
+                {
+                    double pre[PRE], xn[CH];
 #pragma unroll
-                for (int q = 0; q < kPcBlock; ++q)
-                    if (q < npk) nxt[q] = __builtin_nontemporal_load(&p.ut[(size_t)q * NP + chain]);
-                int i = 0, j = 0;
-                double acc = x0;
-                double xn = (D > 1) ? p.x[NP + chain] : 0.0;            // the next column's start value, one column ahead
-                for (int k0 = 0; k0 < npk; k0 += kPcBlock) {
+                    for (int k = 0; k < PRE; ++k) pre[k] = __builtin_nontemporal_load(cut + k * kWave);
 #pragma unroll
-                    for (int q = 0; q < kPcBlock; ++q) cur[q] = nxt[q];
-                    const int k1 = k0 + kPcBlock;
+                    for (int j = 0; j < CH; ++j) xn[j] = p.x[(size_t)(j + 1 < D ? j + 1 : D - 1) * NP + chain];
 #pragma unroll
-                    for (int q = 0; q < kPcBlock; ++q)
-                        if (k1 + q < npk) nxt[q] = __builtin_nontemporal_load(&p.ut[(size_t)(k1 + q) * NP + chain]);
+                    for (int j = 0; j < CH; ++j) {
+                        if (j < P) {
 #pragma unroll
-                    for (int q = 0; q < kPcBlock; ++q) {
-                        if (k0 + q < npk) {
-                            acc += vec[i * kWave] * cur[q];
-                            if (i == j) {
-                                if (live) p.proposed[(size_t)j * NP + chain] = acc;
-                                ++j;
-                                i = 0;
-                                acc = xn;
-                                if (j + 1 < D) xn = p.x[(size_t)(j + 1) * NP + chain];
-                            } else {
-                                ++i;
+                            for (int i = 0; i <= j; ++i) acc += vec[i * kWave] * pre[j * (j + 1) / 2 + i];
+                            pdst[(size_t)j * pstride] = acc;
+                            close_column(xn[j]);
+                        }
+                    }
+                }
+                // the rest in chunks through rotating buffers, as for the covariance.  Columns are now longer than a
+                // chunk: a chunk closes at most the column it starts in, and its fetch brings the start value of the
+                // column behind that one along.  No conditional memory operation in the steady loop: every chunk
+                // stores ONE value to the proposal -- the finished x'[j] of the column it closed, or the running sum
+                // of the column still open, which the chunk that closes it overwrites.
+                double buf[kPcDepth][CH], xs[kPcDepth];
+                const int nch = (npk - kP + CH - 1) / CH;
+                int lrow = 0, lcol = P;                                // loader: (row, column) of a chunk's first element
+                auto fetch = [&](double (&b)[CH], double& xn, int c) {
+                    const double* src = cut + (size_t)(kP + c * CH) * kWave;
+#pragma unroll
+                    for (int q = 0; q < CH; ++q) b[q] = __builtin_nontemporal_load(src + q * kWave);
+                    xn = p.x[(size_t)(lcol + 1 < D ? lcol + 1 : D - 1) * NP + chain];
+                    lrow += CH;
+                    if (lrow > lcol) {
+                        lrow -= lcol + 1;
+                        ++lcol;
+                    }
+                };
+                int ci = 0, cj = P;
+                auto consume = [&](double (&b)[CH], double xn, int c, auto whole) {
+                    constexpr bool WHOLE = decltype(whole)::value;
+                    const int k0 = kP + c * CH;
+                    double sr[CH];
+                    bool end[CH];
+                    const int cj0 = cj < D ? cj : D - 1;
+#pragma unroll
+                    for (int q = 0; q < CH; ++q) {
+                        sr[q] = vec[(ci < D ? ci : 0) * kWave];
+                        end[q] = ci == cj;
+                        ci = end[q] ? 0 : ci + 1;
+                        cj = end[q] ? cj + 1 : cj;
+                    }
+#pragma unroll
+                    for (int q = 0; q < CH; ++q) sr[q] = sr[q] * b[q];
+                    double done = 0.0;
+                    bool closed = false;
+#pragma unroll
+                    for (int q = 0; q < CH; ++q) {
+                        if (WHOLE || k0 + q < npk) {
+                            acc += sr[q];
+                            if (end[q]) {
+                                done = acc;
+                                closed = true;
+                                close_column(xn);
                             }
+                        }
+                    }
+                    pdst[(size_t)cj0 * pstride] = closed ? done : acc;
+                };
+#pragma unroll
+                for (int sl = 0; sl < kPcDepth; ++sl) fetch(buf[sl], xs[sl], sl);
+                int c0 = 0;
+                for (; c0 + 2 * kPcDepth <= nch; c0 += kPcDepth) {
+#pragma unroll
+                    for (int sl = 0; sl < kPcDepth; ++sl) {
+                        consume(buf[sl], xs[sl], c0 + sl, std::true_type{});
+                        fetch(buf[sl], xs[sl], c0 + sl + kPcDepth);
+                    }
+                }
+                for (; c0 < nch; c0 += kPcDepth) {
+#pragma unroll
+                    for (int sl = 0; sl < kPcDepth; ++sl) {
+                        const int c = c0 + sl;
+                        if (c < nch) {
+                            consume(buf[sl], xs[sl], c, std::false_type{});
+                            if (c + kPcDepth < nch) fetch(buf[sl], xs[sl], c + kPcDepth);
                         }
                     }
                 }
@@ -376,7 +529,7 @@ __global__ void __launch_bounds__(kWave, 1) perchain_step_kernel(const PerChainP
                     for (int i2 = 1; i2 < D; ++i2) {
                         const double sr = vec[i2 * kWave];
                         for (int j2 = 0; j2 < i2; ++j2) {
-                            const double u = p.ut[(size_t)(npk + i2 * (i2 - 1) / 2 + j2) * NP + chain];
+                            const double u = cut[(size_t)(npk + i2 * (i2 - 1) / 2 + j2) * kWave];
                             double v = p.proposed[(size_t)j2 * NP + chain];
                             v += sr * u;
                             if (live && ufull) p.proposed[(size_t)j2 * NP + chain] = v;
@@ -387,10 +540,24 @@ __global__ void __launch_bounds__(kWave, 1) perchain_step_kernel(const PerChainP
 
             // ---- StepRMS window (:391-406), likelihood (:410), Metropolis test (:432-463), accept copy (:484-491) ----
             if (p.step_rms_window > 0) {
-                double sqr = 0.0;
-                for (int i = 0; i < D; ++i) {
-                    const double t = p.proposed[(size_t)i * NP + chain] - p.x[(size_t)i * NP + chain];
-                    sqr += t * t;
+                if (!fused) {
+                    sqr = 0.0;
+                    for (int i0 = 0; i0 < D; i0 += kPcBatch) {
+                        double pv[kPcBatch], xv[kPcBatch];
+#pragma unroll
+                        for (int q = 0; q < kPcBatch; ++q) {
+                            const int i = (i0 + q < D) ? i0 + q : D - 1;
+                            pv[q] = p.proposed[(size_t)i * NP + chain];
+                            xv[q] = p.x[(size_t)i * NP + chain];
+                        }
+#pragma unroll
+                        for (int q = 0; q < kPcBatch; ++q) {
+                            if (i0 + q < D) {
+                                const double t = pv[q] - xv[q];
+                                sqr += t * t;
+                            }
+                        }
+                    }
                 }
                 if (live) {
                     double ms = step_rms * step_rms;
@@ -401,7 +568,9 @@ __global__ void __launch_bounds__(kWave, 1) perchain_step_kernel(const PerChainP
                     step_rms = __builtin_sqrt(ms);
                 }
             }
-            const double lp = serial_loglike<LIKE, true>(p.proposed, chain, NP, D, p.like);
+            double lp;
+            if (LIKE == SMCMC_LIKE_ISO_GAUSS && fused) lp = lsum;
+            else lp = serial_loglike<LIKE, true>(p.proposed, chain, NP, D, p.like);
             if (live) {
                 logl_prop = lp;
                 bool take;
@@ -424,7 +593,14 @@ __global__ void __launch_bounds__(kWave, 1) perchain_step_kernel(const PerChainP
                 if (take) {
                     logl = logl_prop;
                     ++naccept;
-                    for (int i = 0; i < D; ++i) p.x[(size_t)i * NP + chain] = p.proposed[(size_t)i * NP + chain];
+                    for (int i0 = 0; i0 < D; i0 += kPcBatch) {
+                        double pv[kPcBatch];
+#pragma unroll
+                        for (int q = 0; q < kPcBatch; ++q) pv[q] = p.proposed[(size_t)((i0 + q < D) ? i0 + q : D - 1) * NP + chain];
+#pragma unroll
+                        for (int q = 0; q < kPcBatch; ++q)
+                            if (i0 + q < D) p.x[(size_t)(i0 + q) * NP + chain] = pv[q];
+                    }
                 }
                 if (p.save_x != nullptr && ((tstep - p.step0) % (uint32_t)p.save_stride) == 0) {
                     const size_t slot = (size_t)((tstep - p.step0) / (uint32_t)p.save_stride - 1u);

@@ -1,6 +1,6 @@
 // Test driver: one chain of sMCMC::TSimpleMCMC<TIsoGaussLogLikelihood> with a frozen covariance (every chain of the
 // FROZEN engine is a reference chain), Step(true, metropolis) nsteps times with the `Step` branch on, the tree written
-// as CSV.  argv: dim nsteps metropolis out.csv.  tests/test_cpp_host.py diffs the Step / Accepted / LogLikelihood
+// as CSV.  argv: dim nsteps metropolis out.csv [exact=1].  tests/test_cpp_host.py diffs the Step / Accepted / LogLikelihood
 // columns against the CPU restatement of TSimpleMCMC.H:370-496 and checks GetProposed() on the way.
 #include <cstdlib>
 #include <iostream>
@@ -12,6 +12,7 @@ int main(int argc, char** argv) {
     try {
         sMCMC::TreeType tree("SimpleMCMC", "");
         sMCMC::TSimpleMCMC<sMCMC::TIsoGaussLogLikelihood> mcmc(&tree, true);
+        if (argc > 5) mcmc.SetExactArithmetic(std::atoi(argv[5]) != 0);
         mcmc.GetProposeStep().SetDim(dim);
         mcmc.GetProposeStep().SetCovarianceFrozen(true);
         sMCMC::Vector p((std::size_t)dim, 0.25);

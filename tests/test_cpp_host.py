@@ -398,3 +398,33 @@ def test_ahmc_example_runs_the_three_phases(gpu, tmp_path):
     # six seeds tried stall, in the CPU restatement alike); what the schedule does bit for bit is
     # tests/test_gpu_hmc.py's job, here only that the program ran its phases and wrote finite points.
     assert np.all(np.isfinite(x))
+
+
+@pytest.mark.gpu
+def test_step_column_with_fast_arithmetic_still_has_the_proposed_point(gpu, tmp_path):
+    """SetExactArithmetic(false) at dim <= 63 runs the kernels that do not keep the proposed point in registers past
+    the accept test: with SMCMC_P_KEEP_PROPOSED (which Start() sets, TSimpleMCMC.H:576 fProposed) they store it, so
+    GetProposed() and the `Step` branch of a REJECTED step are the step that was tried, not a stale buffer.  The
+    driver itself checks accepted == proposed after every move and an unmoved point after every rejection."""
+    exe = str(tmp_path / "step_column.exe")
+    cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-Werror", f"-I{os.path.join(ROOT, 'include')}",
+           os.path.join(ROOT, "tests", "cpp", "step_column.C"), f"-L{LIBDIR}", "-lsmcmc_amd",
+           f"-Wl,-rpath,{LIBDIR}", "-Wl,-rpath,/opt/rocm/lib", "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    dim, nsteps = 5, 200
+    out = tmp_path / "steps.csv"
+    r = subprocess.run([exe, str(dim), str(nsteps), "0", str(out), "0"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = open(out).read().splitlines()
+    col = {h: i for i, h in enumerate(lines[0].split(",")) if h}
+    rows = [l.split(",") for l in lines[1:]]
+    assert len(rows) == nsteps + 1
+    steps = np.array([[float(row[col[f"Step[{k}]"]]) for k in range(dim)] for row in rows[1:]])
+    acc = np.array([[float(row[col[f"Accepted[{k}]"]]) for k in range(dim)] for row in rows])
+    moved = np.any(acc[1:] != acc[:-1], axis=1)
+    assert 0 < moved.sum() < nsteps
+    assert np.all(np.any(steps != 0, axis=1))                    # every entry, rejected ones included, has its trial step
+    assert len({tuple(s) for s in steps}) == nsteps              # ... and a fresh one each time
+    # a moved entry's step is the move (proposed - accepted-before, then accepted = proposed)
+    np.testing.assert_allclose(steps[moved], (acc[1:] - acc[:-1])[moved], rtol=0, atol=1e-15)

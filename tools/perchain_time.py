@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--chains", type=int, nargs="+", default=[4096, 65536])
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--launches", type=int, default=4)
+    ap.add_argument("--frozen", action="store_true", help="SetCovarianceFrozen: the covariance stream is skipped")
     ap.add_argument("--json")
     a = ap.parse_args()
     import torch
@@ -37,6 +38,8 @@ def main():
     rows = []
     for n in a.chains:
         e = pkg.Engine(a.dim, n, mode=pkg.MODE_PER_CHAIN, stream=stream.cuda_stream)
+        if a.frozen:
+            e.SetCovarianceFrozen(True)
         assert e.Start(np.zeros(a.dim))
         e.Step(8)
         torch.cuda.synchronize()

@@ -118,13 +118,65 @@ def _compile(unit):
     if only and name not in only.split(",") and os.path.exists(obj):
         _STALE.append(name)
         return obj, False
-    cmd = [HIPCC] + FLAGS + defs + ["-c", os.path.join(CSRC, src), "-o", obj]
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    if r.returncode != 0:
-        raise RuntimeError(f"hipcc failed for {name}:\n{' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
+    if src in CHECKED_SOURCES and _has_assembly_reads(defs):
+        _compile_checked(src, defs, name, obj)
+    else:
+        cmd = [HIPCC] + FLAGS + defs + ["-c", os.path.join(CSRC, src), "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {name}:\n{' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
     with open(stamp_file, "w") as f:
         f.write(stamp)
     return obj, True
+
+
+# Translation units whose kernels place LDS reads and their waits by hand (inline assembly): compiled with the
+# intermediate files kept, and the device listing checked before the object is accepted (inflight_check.py: the
+# compiler must not touch a register while an assembly read into it is in flight).
+CHECKED_SOURCES = ("smcmc_inst.hip",)
+
+
+class InflightError(RuntimeError):
+    """A unit whose listing failed the in-flight register check (every such unit of a build is reported together)."""
+
+
+def _has_assembly_reads(defs):
+    """kAsmReads<DP> of smcmc_kernels.hip.h: the families from 47 dimensions up place their LDS reads by hand."""
+    for d in defs:
+        m = re.match(r"-DSMCMC_DP=(\d+)$", d)
+        if m:
+            return int(m.group(1)) >= 47
+    return True
+
+
+def _compile_checked(src, defs, name, obj):
+    import glob
+    import shutil
+    if HERE not in sys.path:
+        sys.path.insert(0, HERE)
+    import inflight_check
+    tmp = os.path.join(OBJ_DIR, "tmp_" + name)
+    shutil.rmtree(tmp, ignore_errors=True)
+    os.makedirs(tmp)
+    try:
+        tmp_obj = os.path.join(tmp, name + ".o")
+        cmd = [HIPCC] + FLAGS + defs + ["-save-temps=obj", "-c", os.path.join(CSRC, src), "-o", tmp_obj]
+        r = subprocess.run(cmd, capture_output=True, text=True, cwd=tmp)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {name}:\n{' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
+        listings = glob.glob(os.path.join(tmp, f"*amdgcn*{ARCH}*.s"))
+        if len(listings) != 1:
+            raise RuntimeError(f"{name}: expected one device listing from -save-temps, found {listings}")
+        report = []
+        for kernel, reads, findings in inflight_check.check_listing(listings[0]):
+            for idx, text, regs in findings[:6]:
+                report.append(f"  {kernel} +{idx}: {text}   (assembly read in flight into v{regs})")
+        if report:
+            raise InflightError(f"{name}: the compiler touches registers with a hand-placed LDS read in flight "
+                                f"(see inflight_check.py):\n" + "\n".join(report[:40]))
+        os.replace(tmp_obj, obj)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def _link(objs, lib_path):
@@ -161,11 +213,20 @@ def build(jobs=None, verbose=False, user_likelihood=None, output=None, with_plai
             todo.append(u)
     jobs = jobs or min(8, os.cpu_count() or 1)
     built = {}
+    refused = []
     with concurrent.futures.ThreadPoolExecutor(max_workers=jobs) as pool:
-        for unit, (obj, did) in zip(todo, pool.map(_compile, todo)):
+        futures = [(unit, pool.submit(_compile, unit)) for unit in todo]
+        for unit, fut in futures:
+            try:
+                obj, did = fut.result()
+            except InflightError as exc:
+                refused.append(str(exc))
+                continue
             built[unit[2]] = (obj, did)
             if verbose and did:
                 print("built", os.path.basename(obj), flush=True)
+    if refused:
+        raise InflightError("\n".join(refused))
     if _STALE:
         # a development shortcut, never a release build: objects of different source states may disagree about shared
         # structs (StepParams, PanelParams, ...)

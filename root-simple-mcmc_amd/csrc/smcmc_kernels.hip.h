@@ -64,17 +64,34 @@ __device__ __forceinline__ cptr_f64 as_const(const double* p) {
 // The two entries come in ahead of the arithmetic (normal_tables_fetch): an LDS read returns in issue order, so a
 // table read issued behind the prefetch of the next U piece would wait for the whole piece.
 struct NormalTables { f64x2 le, ae; };
-// (inline assembly for the same reason as load_piece: the wait is normal_tables_ready, placed by the caller)
+// Hand-placed LDS reads (inline assembly, waited for by hand: load_piece below says why) are only used where the
+// compiler leaves them alone.  It sees an assembly read's destination as an ordinarily defined value and may copy or
+// spill it at once -- before the data has arrived.  The families up to 31 dimensions, which it allocates for two
+// wavefronts per SIMD, are short of registers and did exactly that (v_accvgpr_write right behind the read); they keep
+// reads the compiler can see and count.  build.py runs inflight_check.py over every step-kernel listing and fails on
+// a compiler instruction that touches a register with an assembly read in flight.
+template <int DP>
+constexpr bool kAsmReads = DP >= 47;
+template <bool ASM>
 __device__ __forceinline__ NormalTables normal_tables_fetch(uint32_t w0, uint32_t w1, uint32_t lt_base, uint32_t at_base) {
     NormalTables t;
     const uint32_t la = lt_base + 16u * smcmc_normal_log_index(w0), aa = at_base + 16u * smcmc_normal_angle_index(w1);
-    asm volatile("ds_read_b128 %0, %1" : "=v"(t.le) : "v"(la));
-    asm volatile("ds_read_b128 %0, %1" : "=v"(t.ae) : "v"(aa));
+    if constexpr (ASM) {
+        asm volatile("ds_read_b128 %0, %1" : "=v"(t.le) : "v"(la));
+        asm volatile("ds_read_b128 %0, %1" : "=v"(t.ae) : "v"(aa));
+    } else {
+        t.le = *(volatile lds_cptr_f64x2)(uintptr_t)la;
+        t.ae = *(volatile lds_cptr_f64x2)(uintptr_t)aa;
+    }
     return t;
 }
-template <int N>
+template <int N, bool ASM>
 __device__ __forceinline__ void normal_tables_ready(NormalTables& a, NormalTables& b) {
-    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a.le), "+v"(a.ae), "+v"(b.le), "+v"(b.ae) : "n"(N));
+    if constexpr (ASM) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a.le), "+v"(a.ae), "+v"(b.le), "+v"(b.ae) : "n"(N));
+}
+template <int N, bool ASM>
+__device__ __forceinline__ void normal_tables_ready(NormalTables& a) {
+    if constexpr (ASM) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a.le), "+v"(a.ae) : "n"(N));
 }
 __device__ __forceinline__ void normal_pair_lds(uint32_t w0, uint32_t w1, const NormalTables& t, double* n0, double* n1) {
 #define SMCMC_LT_LDS(k, c) (t.le[c])
@@ -171,8 +188,11 @@ template <int DP, bool FULLU, int i, int c, int k = 0>
 __device__ __forceinline__ void load_piece(uint32_t ubase, f64x2 (&dst)[kPiece / 2]) {
     typedef ULayout<DP, FULLU> UL;
     if constexpr (k < kPiece / 2) {
-        if constexpr (c + 2 * k < UL::DPE)
-            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[k]) : "v"(ubase), "n"((UL::off(i) + (c - UL::j0(i)) + 2 * k) * 8));
+        if constexpr (c + 2 * k < UL::DPE) {
+            constexpr int off = (UL::off(i) + (c - UL::j0(i)) + 2 * k) * 8;
+            if constexpr (kAsmReads<DP>) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[k]) : "v"(ubase), "n"(off));
+            else dst[k] = *(lds_cptr_f64x2)(uintptr_t)(ubase + (uint32_t)off);
+        }
         load_piece<DP, FULLU, i, c, k + 1>(ubase, dst);
     }
 }
@@ -184,10 +204,11 @@ constexpr int piece_reads() {
     return n;
 }
 // every LDS read older than the N youngest has returned; `piece` is the piece those older reads filled (its first M pairs)
-template <int N, int M>
+template <int N, int M, bool ASM>
 __device__ __forceinline__ void piece_ready(f64x2 (&q)[kPiece / 2]) {
     static_assert(kPiece == 16 && N >= 0 && N < 16 && M >= 1 && M <= 8, "eight register pairs per piece, a 4-bit counter");
-    if constexpr (M == 8) asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]), "+v"(q[6]), "+v"(q[7]) : "n"(N));
+    if constexpr (!ASM) return;
+    else if constexpr (M == 8) asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]), "+v"(q[6]), "+v"(q[7]) : "n"(N));
     else if constexpr (M == 7) asm volatile("s_waitcnt lgkmcnt(%7)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]), "+v"(q[6]) : "n"(N));
     else if constexpr (M == 6) asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]) : "n"(N));
     else if constexpr (M == 5) asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]) : "n"(N));
@@ -499,8 +520,11 @@ __global__ void __launch_bounds__(kWave, 2) step_kernel(const StepParams p) {
     }
     __syncthreads();
 
-    // operand prefetch of the fold (fetch_operands): only where a k-quad's matrix instructions span several pieces
-    constexpr bool OPF = MOMENTS && NT >= 3;
+    // operand prefetch of the fold (fetch_operands): only where a k-quad's matrix instructions span several pieces, only
+    // with the other hand-placed reads (kAsmReads), and only in the common kernels (triangular decomposition, no
+    // uniform dimensions / scan): in the 63-dimension family the others are short of registers and the compiler
+    // spilled the prefetched operands behind their reads (found by the build's listing check)
+    constexpr bool OPF = MOMENTS && T >= 3 && kAsmReads<DP> && !FULLU && !SPECIAL;
     double raw[OPF ? T : 1], raws = 0.0;
     uint32_t xaddr[OPF ? T : 1], xsaddr = 0;
     if constexpr (OPF) {
@@ -690,13 +714,14 @@ __global__ void __launch_bounds__(kWave, 2) step_kernel(const StepParams p) {
             if ((uint32_t)b == (aw >> 2)) uword = smcmc_select_word(blk, aw & 3u);
             // LDS reads of the block, in this order (they return in issue order): the table entries of its two pairs of
             // normals, then the first piece of U, which stays in flight under the normals' arithmetic
-            NormalTables t0 = normal_tables_fetch(blk.v[0], blk.v[1], ltab, atab);
-            NormalTables t1 = t0;
-            if constexpr (4 * b + 2 < DP) t1 = normal_tables_fetch(blk.v[2], blk.v[3], ltab, atab);
+            NormalTables t0 = normal_tables_fetch<kAsmReads<DP>>(blk.v[0], blk.v[1], ltab, atab);
+            NormalTables t1;   // (never a copy of t0: a copy of registers whose read is still in flight copies what was there before)
+            if constexpr (4 * b + 2 < DP) t1 = normal_tables_fetch<kAsmReads<DP>>(blk.v[2], blk.v[3], ltab, atab);
             {
                 constexpr int i0 = PC::row(0), c0p = PC::col(0);
                 load_piece<DP, FULLU, i0, c0p>(up, cur);
-                normal_tables_ready<piece_reads<DP, FULLU, c0p>()>(t0, t1);
+                if constexpr (4 * b + 2 < DP) normal_tables_ready<piece_reads<DP, FULLU, c0p>(), kAsmReads<DP>>(t0, t1);
+                else normal_tables_ready<piece_reads<DP, FULLU, c0p>(), kAsmReads<DP>>(t0);
             }
             double n[4];
             normal_pair_lds(blk.v[0], blk.v[1], t0, &n[0], &n[1]);
@@ -713,9 +738,9 @@ __global__ void __launch_bounds__(kWave, 2) step_kernel(const StepParams p) {
                 if constexpr (r + 1 < PC::COUNT) {
                     constexpr int i1 = PC::row(r + 1), c1 = PC::col(r + 1);
                     load_piece<DP, FULLU, i1, c1>(up, nxt);
-                    piece_ready<piece_reads<DP, FULLU, c1>(), piece_reads<DP, FULLU, c>()>(cur);
+                    piece_ready<piece_reads<DP, FULLU, c1>(), piece_reads<DP, FULLU, c>(), kAsmReads<DP>>(cur);
                 } else {
-                    piece_ready<0, piece_reads<DP, FULLU, c>()>(cur);
+                    piece_ready<0, piece_reads<DP, FULLU, c>(), kAsmReads<DP>>(cur);
                 }
                 const double srow = sr[i - 4 * b];
 #pragma unroll

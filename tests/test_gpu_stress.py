@@ -100,7 +100,7 @@ def test_stress_likelihoods_reference_dimensions(gpu, oracle, kind, dim, mode):
     assert e.lane("naccept").sum() > 0
 
 
-def test_stress_likelihoods_unsupported_corners(gpu):
+def test_stress_likelihoods_unsupported_corners(gpu, oracle):
     # fused order for dim > 63 is the matrix-pipe kernel, which carries the three smooth likelihoods only
     e = gpu.Engine(100, 64, likelihood=ASYM, exact=False)
     assert e.Start(np.zeros(100))
@@ -115,11 +115,17 @@ def test_stress_likelihoods_unsupported_corners(gpu):
     # wrong parameter count
     with pytest.raises(gpu.SmcmcError):
         gpu.Engine(25, 64, likelihood=CONSTRAINED, likelihood_params=np.ones(10)).Start(np.zeros(25))
-    # no gradient: not an HMC target
+    # no gradient of their own: HMC targets only through the gradient types that do not ask the functor for one
+    # (TSimpleHMC.H:417-454, 524-528; tests/test_gpu_hmc.py::test_hmc_targets_without_a_gradient) -- the default type
+    # calls the functor's gradient, which the reference's stress functors answer with an exception
     for kind in (ASYM, HORRIFIC, CONSTRAINED):
+        prm = oracle.like_params(kind, 25)
+        h = gpu.HmcEngine(25, 64, likelihood=kind, likelihood_params=prm if prm.size else None)
+        h.Start(np.full(25, 0.01))
         with pytest.raises(gpu.SmcmcError) as err:
-            gpu.HmcEngine(25, 64, likelihood=kind)
-        assert err.value.status == 5   # SMCMC_ERR_UNSUPPORTED
+            h.Step(1, gradient_type=0)
+        assert err.value.status == 3   # SMCMC_ERR_RUNTIME
+        h.close()
 
 
 def test_constrained_posterior_known_answer(gpu, oracle):

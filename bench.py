@@ -160,11 +160,12 @@ def extra_metropolis(pkg, torch, stream, name, dim, chains, like, like_id, prm, 
     return out
 
 
-def extra_perchain(pkg, torch, stream, dim, chains, steps, launches):
+def extra_perchain(pkg, torch, stream, dim, chains, steps, launches, header_form=False):
     """SMCMC_MODE_PER_CHAIN: every chain adapts its own covariance every step and decomposes it on its own schedule --
     the reference's own mode, the one configuration whose HBM traffic per chain-step is O(D^2): the chain's packed
     decomposition is read, its packed covariance read and written (8 * 3 * D (D + 1) / 2 bytes) on top of the O(D) state."""
-    eng = pkg.Engine(dim, chains, seed=20240607, mode=pkg.MODE_PER_CHAIN, stream=stream.cuda_stream)
+    kw = {"likelihood": pkg.LIKE_QUADFORM, "likelihood_params": tdummy_error(dim)} if header_form else {}
+    eng = pkg.Engine(dim, chains, seed=20240607, mode=pkg.MODE_PER_CHAIN, stream=stream.cuda_stream, **kw)
     assert eng.Start(np.zeros(dim))
     eng.Step(8)
     torch.cuda.synchronize()
@@ -179,8 +180,8 @@ def extra_perchain(pkg, torch, stream, dim, chains, steps, launches):
     kms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
     rate = chains * steps * launches / dt
     nbytes = 8 * 3 * dim * (dim + 1) // 2 + 8 * 7 * dim + 16
-    out = {"workload": "TDummyLogLikelihood README form D=%d, %d chains, TProposeAdaptiveStep per chain (own covariance "
-                       "every step, own UpdateProposal schedule)" % (dim, chains),
+    out = {"workload": "TDummyLogLikelihood %s form D=%d, %d chains, TProposeAdaptiveStep per chain (own covariance "
+                       "every step, own UpdateProposal schedule)" % ("header" if header_form else "README", dim, chains),
            "chain_steps_per_s": rate, "kernel_chain_steps_per_s": chains * steps / (kms * 1e-3),
            "us_per_ensemble_step": kms * 1e3 / steps, "steps_per_launch": steps, "launches": launches,
            "algorithmic_bytes_per_chain_step": nbytes, "hbm_GBps": chains * steps / (kms * 1e-3) * nbytes / 1e9,
@@ -449,6 +450,7 @@ def main():
             # the D = 500 engines below have come and gone the same row reads 395 us per step instead of 370)
             extra["perchain_d50_65536"] = extra_perchain(pkg, torch, stream, 50, 65536, 64, 3)
             extra["perchain_d50_4096"] = extra_perchain(pkg, torch, stream, 50, 4096, 64, 3)
+            extra["perchain_d50_65536_header_tdummy"] = extra_perchain(pkg, torch, stream, 50, 65536, 64, 3, header_form=True)
             extra["c2_readme_iso_d50_65536_pooled_fused"] = extra_metropolis(
                 pkg, torch, stream, "the headline's workload in the fused order (fma where the reference has multiply + add; "
                 "each lane bit for bit the fused-order restatement)", 50, CHAINS_PER_GPU, "iso", pkg.LIKE_ISO_GAUSS, None,

@@ -98,6 +98,27 @@ __device__ __forceinline__ void pc_unpack(int k, int& i, int& j) {
     j = k - i * (i + 1) / 2;
 }
 
+// TDummyLogLikelihood.H:24-28 for the point held in a column of LDS (v[j * kWave]): logL -= 0.5 p[i] Error(j, i) p[j], i outer,
+// j inner, un-fused -- the arithmetic of quadform_serial (smcmc_panel_kernel.hip.h), which walks the [dim][chain] image
+// in device memory instead: D^2 loads per chain-step that a lone wavefront has nothing to hide behind.
+__device__ __forceinline__ double pc_quadform_lds(const double* v, cptr_f64 et, int D) {
+    double logl = 0.0;
+    for (int i = 0; i < D; ++i) {
+        const double h = 0.5 * v[i * kWave];
+        const cptr_f64 erow = et + (size_t)i * D;
+        int j = 0;
+        for (; j + kPcBatch <= D; j += kPcBatch) {
+            double pj[kPcBatch];
+#pragma unroll
+            for (int u = 0; u < kPcBatch; ++u) pj[u] = v[(j + u) * kWave];
+#pragma unroll
+            for (int u = 0; u < kPcBatch; ++u) logl -= h * erow[j + u] * pj[u];
+        }
+        for (; j < D; ++j) logl -= h * erow[j] * v[j * kWave];
+    }
+    return logl;
+}
+
 template <int LIKE>
 __global__ void __launch_bounds__(kWave, 1) perchain_step_kernel(const PerChainParams p) {
     extern __shared__ double lds[];   // vec[i * 64 + lane] (the diffs x - c, then sigma * r), or R[64][65] of the Cholesky
@@ -569,8 +590,23 @@ __global__ void __launch_bounds__(kWave, 1) perchain_step_kernel(const PerChainP
                 }
             }
             double lp;
-            if (LIKE == SMCMC_LIKE_ISO_GAUSS && fused) lp = lsum;
-            else lp = serial_loglike<LIKE, true>(p.proposed, chain, NP, D, p.like);
+            if (LIKE == SMCMC_LIKE_ISO_GAUSS && fused) {
+                lp = lsum;
+            } else if constexpr (LIKE == SMCMC_LIKE_QUADFORM) {
+                // the D^2-term sum reads the proposal D times over: from LDS (the scaled normals are done with)
+                __syncthreads();
+                for (int i0 = 0; i0 < D; i0 += kPcBatch) {
+                    double pv[kPcBatch];
+#pragma unroll
+                    for (int q = 0; q < kPcBatch; ++q) pv[q] = p.proposed[(size_t)((i0 + q < D) ? i0 + q : D - 1) * NP + chain];
+#pragma unroll
+                    for (int q = 0; q < kPcBatch; ++q)
+                        if (i0 + q < D) vec[(i0 + q) * kWave] = pv[q];
+                }
+                lp = pc_quadform_lds(vec, as_const(p.like), D);
+            } else {
+                lp = serial_loglike<LIKE, true>(p.proposed, chain, NP, D, p.like);
+            }
             if (live) {
                 logl_prop = lp;
                 bool take;

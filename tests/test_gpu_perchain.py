@@ -274,3 +274,19 @@ def test_config1_a_million_adaptive_steps(gpu, oracle):
     cov = np.array([e.chain_proposal(c)[1] for c in range(n)])
     assert np.max(np.abs(centre.mean(axis=0))) < 0.2            # 64 windows of ~10 independent points each
     assert np.max(np.abs(cov.mean(axis=0) - np.eye(dim))) < 0.25
+
+
+def test_the_full_ensemble_sampled_lanes(gpu, oracle):
+    """BASELINE config 2 at its full size in this mode: 65 536 chains (1 024 wavefront tiles of covariance and
+    decomposition, 2.1 GB), a few hundred steps through an UpdateProposal of every chain; lanes from the first, a middle
+    and the last tile against their reference chains.  Chains are independent here, so sampled lanes are the whole check."""
+    dim, n = 50, 65536
+    which = (0, 63, 64, 32767, 32768, 65471, 65472, 65535)
+    e, chains = _make(gpu, oracle, dim, n, 0, which=which,
+                      setup=lambda o: (o.SetAcceptanceWindow if hasattr(o, "SetAcceptanceWindow") else o.set_acceptance_window)(60))
+    _both(e, chains, "SetNextUpdate", "set_next_update", 40)
+    _step(e, chains, 400)
+    _same(e, chains, "full ensemble")
+    assert np.all(e.lane("update_count") >= 2)
+    assert np.all(e.lane("chain_steps") == 400)
+    e.close()

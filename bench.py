@@ -125,14 +125,19 @@ def fractions(rate, dim, like):
 
 
 def extra_metropolis(pkg, torch, stream, name, dim, chains, like, like_id, prm, x0, exact, windows, window=WINDOW,
-                     stride=1):
+                     stride=1, dense_quadform=None):
     """One of the other BASELINE configs: pooled covariance, `window` steps then a sync, timed with HIP events on the
     engine's stream (device time of the step launches, moment folds included) and with the wall clock (sync included)."""
     eng = pkg.Engine(dim, chains, likelihood=like_id, likelihood_params=prm, seed=20240607, mode=pkg.MODE_POOLED,
                      exact=exact, stream=stream.cuda_stream)
     if dim > 63:
         eng.set_param("MOMENT_STRIDE", stride)
+    if dense_quadform is not None:
+        eng.set_param("DENSE_QUADFORM", 1.0 if dense_quadform else 0.0)
     assert eng.Start(x0)
+    quadform_walk = None
+    if like_id == pkg.LIKE_QUADFORM:
+        quadform_walk = "dense D^2-term sum" if eng.get_param("DENSE_QUADFORM") else "non-zero entries of Error only (bit for bit the dense sum)"
     eng.Step(window); eng.sync()                      # warm-up window
     torch.cuda.synchronize()
     gc.collect(); gc.disable()                        # a full collection of a torch-sized heap stalls the host for ~70 ms
@@ -155,6 +160,8 @@ def extra_metropolis(pkg, torch, stream, name, dim, chains, like, like_id, prm, 
            "arithmetic": "reference-order" if exact else "fused (matrix pipe)" if dim > 63 else "fused",
            "moment_stride": stride,
            "accept_rate": float(eng.lane("naccept").sum() / (eng.get_param("TOTAL_STEPS") * chains))}
+    if quadform_walk:
+        out["quadratic_form"] = quadform_walk
     out.update(fractions(rate, dim, like))
     eng.close()
     return out
@@ -445,7 +452,11 @@ def main():
         try:
             extra["c2_header_tdummy"] = extra_metropolis(
                 pkg, torch, stream, "TDummyLogLikelihood header form (quadratic form) D=50, 65 536 chains, pooled", 50,
-                CHAINS_PER_GPU, "quadform", pkg.LIKE_QUADFORM, tdummy_error(50), np.zeros(50), True, 20)
+                CHAINS_PER_GPU, "quadform", pkg.LIKE_QUADFORM, tdummy_error(50), np.zeros(50), True, 20, dense_quadform=True)
+            extra["c2_header_tdummy_sparse_walk"] = extra_metropolis(
+                pkg, torch, stream, "TDummyLogLikelihood header form D=50, 65 536 chains, pooled; its Error matrix is the "
+                "identity plus one correlated pair, and the serial sum walks the 52 non-zero entries", 50,
+                CHAINS_PER_GPU, "quadform", pkg.LIKE_QUADFORM, tdummy_error(50), np.zeros(50), True, 20, dense_quadform=False)
             # (first: 2 GB of per-chain state streamed every step is at its best in freshly allocated memory -- after
             # the D = 500 engines below have come and gone the same row reads 395 us per step instead of 370)
             extra["perchain_d50_65536"] = extra_perchain(pkg, torch, stream, 50, 65536, 64, 3)
@@ -470,7 +481,11 @@ def main():
             extra["c4_share_d500_32768_pooled_header_tdummy"] = extra_metropolis(
                 pkg, torch, stream, "TDummyLogLikelihood header form D=500, 32 768 chains, pooled (the likelihood config 4 "
                 "names, in the reference's order: one serial D^2-term sum per chain)", 500, 32768, "quadform",
-                pkg.LIKE_QUADFORM, tdummy_error(500), np.zeros(500), True, 1)
+                pkg.LIKE_QUADFORM, tdummy_error(500), np.zeros(500), True, 1, dense_quadform=True)
+            extra["c4_share_d500_32768_pooled_header_tdummy_sparse_walk"] = extra_metropolis(
+                pkg, torch, stream, "TDummyLogLikelihood header form D=500, 32 768 chains, pooled, reference order; the serial "
+                "sum walks the 502 non-zero entries of Error", 500, 32768, "quadform",
+                pkg.LIKE_QUADFORM, tdummy_error(500), np.zeros(500), True, 5, dense_quadform=False)
             extra["c4_share_d500_32768_pooled_header_tdummy_fused"] = extra_metropolis(
                 pkg, torch, stream, "TDummyLogLikelihood header form D=500, 32 768 chains, pooled", 500, 32768, "quadform",
                 pkg.LIKE_QUADFORM, tdummy_error(500), np.zeros(500), False, 5)

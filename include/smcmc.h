@@ -110,6 +110,11 @@ typedef enum {
                                          * window late.  0 (default): parity mode */
     SMCMC_P_COVARIANCE_FROZEN = 23,     /* Set/GetCovarianceFrozen :937-938 inside SMCMC_MODE_PER_CHAIN: the covariance loop is
                                          * skipped, the centre still runs (SMCMC_MODE_FROZEN is the shared-decomposition form) */
+    SMCMC_P_DENSE_QUADFORM = 24,        /* SMCMC_LIKE_QUADFORM: 1 = always the dense D^2-term sum.  0 (default): when the Error matrix is
+                                         * sparse (at most a quarter of its entries non-zero, full diagonal, all finite) the serial sums
+                                         * of the reference-order kernels and of SMCMC_MODE_PER_CHAIN walk its non-zero entries only --
+                                         * bit for bit the dense sum (a skipped term is +-0), dense again for a non-finite point.
+                                         * Reads back 1 whenever the dense sum is what runs. */
     SMCMC_P_COUNT_
 } smcmc_param;
 

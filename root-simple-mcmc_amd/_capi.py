@@ -20,7 +20,7 @@ PARAMS = ["COVARIANCE_WINDOW", "COVARIANCE_DEWEIGHT", "ACCEPTANCE_WINDOW", "ACCE
           "ACCEPTANCE_RIGIDITY", "TARGET_ACCEPTANCE", "SIGMA", "MAXIMUM_CORRELATION", "STEP_RMS_WINDOW",
           "NEXT_UPDATE", "COVARIANCE_TRIALS", "CENTER_TRIALS", "COVARIANCE_TRACE", "TOTAL_STEPS",
           "SIGMA_TRACE", "UPDATE_COUNT", "LAST_UPDATE_PATH", "EXACT_ARITHMETIC", "MOMENT_STRIDE", "MOMENT_GROUP", "KEEP_PROPOSED",
-          "DEVICE_UPDATE", "OVERLAP_UPDATE", "COVARIANCE_FROZEN"]
+          "DEVICE_UPDATE", "OVERLAP_UPDATE", "COVARIANCE_FROZEN", "DENSE_QUADFORM"]
 P = {name: i for i, name in enumerate(PARAMS)}
 LANE_F64 = {name: i for i, name in enumerate(
     ["logl", "sigma", "acceptance", "acceptance_trials", "rigidity", "last_value", "last_x0", "step_rms",

@@ -97,6 +97,12 @@ struct smcmc_engine {
     double* d_U = nullptr;
     double* d_Uop = nullptr;       // large dimensions, fused order: U^T in matrix-operand order (smcmc_panel_mfma_kernel.hip.h)
     double* d_like = nullptr;
+    // QUADFORM with a sparse Error matrix: the non-zero entries of Error^T, row by row (quadform_csr); nullptr = dense only
+    int32_t* d_like_rowptr = nullptr;
+    int32_t* d_like_cols = nullptr;
+    double* d_like_vals = nullptr;
+    int like_nnz = 0;
+    bool dense_quadform = false;   // SMCMC_P_DENSE_QUADFORM
     double* d_c0 = nullptr;
     double* d_gacc = nullptr;
     double* d_moments = nullptr;
@@ -293,6 +299,37 @@ int upload_shared(smcmc_engine* h) {
     return SMCMC_OK;
 }
 
+// The compressed form of Error^T for the serial (reference-order / one lane per chain) quadratic forms.  Taken when the
+// matrix is finite, has a full diagonal (so that a non-finite coordinate always shows in the sparse sum, which then
+// falls back on the dense one) and at most a quarter of its entries are non-zero.
+int upload_like_csr(smcmc_engine* h) {
+    (void)hipFree(h->d_like_rowptr); (void)hipFree(h->d_like_cols); (void)hipFree(h->d_like_vals);
+    h->d_like_rowptr = nullptr; h->d_like_cols = nullptr; h->d_like_vals = nullptr; h->like_nnz = 0;
+    if (h->likelihood != SMCMC_LIKE_QUADFORM || h->dense_quadform) return SMCMC_OK;
+    const int D = h->dim;
+    std::vector<int32_t> rowptr(D + 1, 0), cols;
+    std::vector<double> vals;
+    for (int i = 0; i < D; ++i) {
+        for (int j = 0; j < D; ++j) {
+            const double e = h->like_params[(size_t)j * D + i];                  // Error(j, i) = Error^T(i, j)
+            if (!std::isfinite(e)) return SMCMC_OK;
+            if (i == j && e == 0.0) return SMCMC_OK;
+            if (e != 0.0) { cols.push_back(j); vals.push_back(e); }
+        }
+        rowptr[i + 1] = (int32_t)cols.size();
+    }
+    if (cols.size() * 4 > (size_t)D * D) return SMCMC_OK;
+    HIP_TRY(h, hipMalloc(&h->d_like_rowptr, sizeof(int32_t) * rowptr.size()));
+    HIP_TRY(h, hipMalloc(&h->d_like_cols, sizeof(int32_t) * cols.size()));
+    HIP_TRY(h, hipMalloc(&h->d_like_vals, sizeof(double) * vals.size()));
+    HIP_TRY(h, hipMemcpyAsync(h->d_like_rowptr, rowptr.data(), sizeof(int32_t) * rowptr.size(), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_like_cols, cols.data(), sizeof(int32_t) * cols.size(), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_like_vals, vals.data(), sizeof(double) * vals.size(), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->like_nnz = (int)cols.size();
+    return SMCMC_OK;
+}
+
 int upload_like(smcmc_engine* h) {
     if (h->panel_w && !h->d_scratch && (h->likelihood == SMCMC_LIKE_USER || h->likelihood == SMCMC_LIKE_CONSTRAINED)) {
         // large dimensions: one lane per chain evaluates these from the proposal's [dim][chain] image
@@ -303,6 +340,7 @@ int upload_like(smcmc_engine* h) {
         if ((int)h->like_params.size() != h->dim * h->dim)
             return fail(h, SMCMC_ERR_INVALID, "QUADFORM needs dim*dim likelihood parameters (the Error matrix)");
         const int D = h->dim;
+        { int stc_ = upload_like_csr(h); if (stc_) return stc_; }
         if ((h->panel_w && h->exact) || h->mode == SMCMC_MODE_PER_CHAIN) {
             // large dimensions, reference order (and the per-chain kernel at any dimension): one lane per chain walks the
             // D^2-term sum of TDummyLogLikelihood.H:24-28 with j innermost; it reads row i of Error^T (scalar loads) and
@@ -785,6 +823,7 @@ PerChainParams pc_params(smcmc_engine* h, const StepParams& p) {
     q.nchains = p.nchains; q.npad = p.npad; q.dim = p.dim; q.metropolis = p.metropolis;
     q.step0 = h->total_steps; q.target_step = h->total_steps + (uint32_t)p.nsteps;
     q.chain_offset = p.chain_offset; q.seed = p.seed; q.like = h->d_like;
+    q.like_csr = QuadCsr{h->d_like_rowptr, h->d_like_cols, h->d_like_vals};
     q.target = p.target; q.acc_window = p.acc_window; q.asig = p.asig; q.max_up = p.max_up;
     pc_deweights(P, q.acc_w, q.acc_wW, q.cov_w, q.cov_wW);
     q.cov_window = P.covWindow; q.cov_frozen = h->pc_frozen ? 1 : 0;
@@ -841,6 +880,7 @@ StepParams make_params(smcmc_engine* h, int nsteps, int metropolis) {
     p.chain_offset = h->chain_offset;
     p.seed = h->seed;
     p.U = h->d_U; p.like = h->d_like; p.c0 = h->d_c0;
+    p.like_rowptr = h->d_like_rowptr; p.like_cols = h->d_like_cols; p.like_vals = h->d_like_vals;
     p.target = P.target;
     p.acc_window = P.acceptanceWindow;
     double asig = P.target * (1.0 - P.target);              // TSimpleMCMC.H:1746-1747
@@ -922,6 +962,7 @@ int launch(smcmc_engine* h, int nsteps, int metropolis, int stride, double* save
         q.nchains = p.nchains; q.npad = p.npad; q.dim = p.dim; q.metropolis = p.metropolis;
         q.chain_offset = p.chain_offset; q.seed = p.seed;
         q.Uperm = h->d_U; q.like = h->d_like;
+        q.like_csr = QuadCsr{h->d_like_rowptr, h->d_like_cols, h->d_like_vals};
         q.target = p.target; q.acc_window = p.acc_window; q.asig = p.asig; q.max_up = p.max_up;
         q.acc_w = p.acc_w; q.acc_wW = p.acc_wW; q.per_lane_update = p.per_lane_update;
         q.step_rms_window = p.step_rms_window; q.full_u = h->prop->decompFull ? 1 : 0;
@@ -1140,7 +1181,7 @@ int smcmc_destroy(smcmc_engine* h) {
     ON_DEVICE(h);
     if (h->d_x) (void)hipStreamSynchronize(h->stream);
     (void)hipFree(h->d_x); (void)hipFree(h->d_forced); (void)hipFree(h->d_proposed); (void)hipFree(h->d_scratch); (void)hipFree(h->d_uniform); (void)hipFree(h->d_lane_f64); (void)hipFree(h->d_lane_i32);
-    (void)hipFree(h->d_U); (void)hipFree(h->d_Uop); (void)hipFree(h->d_like); (void)hipFree(h->d_c0); (void)hipFree(h->d_gacc);
+    (void)hipFree(h->d_U); (void)hipFree(h->d_Uop); (void)hipFree(h->d_like); (void)hipFree(h->d_like_rowptr); (void)hipFree(h->d_like_cols); (void)hipFree(h->d_like_vals); (void)hipFree(h->d_c0); (void)hipFree(h->d_gacc);
     (void)hipFree(h->d_moments); (void)hipFree(h->d_chunks); (void)hipHostFree(h->h_moments);
     (void)hipFree(h->d_centre); (void)hipFree(h->d_cov); (void)hipFree(h->d_decomp); (void)hipFree(h->d_scal);
     (void)hipFree(h->d_ring); (void)hipFree(h->d_ring_logl);
@@ -1283,6 +1324,9 @@ int smcmc_set_param(smcmc_engine* h, int which, double v) {
             P.centreTrials = v;
             return (per_chain(h) && h->started) ? broadcast_lane_f64(h, SMCMC_LANE_CENTER_TRIALS, v) : SMCMC_OK;
         case SMCMC_P_COVARIANCE_FROZEN: h->pc_frozen = (v != 0.0); return SMCMC_OK;
+        case SMCMC_P_DENSE_QUADFORM:
+            h->dense_quadform = (v != 0.0);
+            return (h->started && h->likelihood == SMCMC_LIKE_QUADFORM) ? upload_like_csr(h) : SMCMC_OK;
         case SMCMC_P_EXACT_ARITHMETIC:
             h->exact = (v != 0.0);
             if (h->started) {                                  // the fused order keeps its own operand images
@@ -1392,6 +1436,7 @@ int smcmc_get_param(smcmc_engine* h, int which, double* out) {
         case SMCMC_P_DEVICE_UPDATE: *out = h->device_update ? 1.0 : 0.0; break;
         case SMCMC_P_OVERLAP_UPDATE: *out = h->overlap_update ? 1.0 : 0.0; break;
         case SMCMC_P_COVARIANCE_FROZEN: *out = (h->pc_frozen || h->mode == SMCMC_MODE_FROZEN) ? 1.0 : 0.0; break;
+        case SMCMC_P_DENSE_QUADFORM: *out = (h->dense_quadform || h->d_like_rowptr == nullptr) ? 1.0 : 0.0; break;
         default: return fail(h, SMCMC_ERR_INVALID, "unknown parameter");
     }
     return SMCMC_OK;

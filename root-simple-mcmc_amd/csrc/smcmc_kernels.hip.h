@@ -258,6 +258,9 @@ struct StepParams {
     uint64_t seed;
     const double* U;           // [DP][DP], zero padded
     const double* like;        // QUADFORM: Error [DP][DP] zero padded; ROSENBROCK: {b}
+    const int32_t* like_rowptr;   // QUADFORM with a sparse Error: its non-zero entries (QuadCsr below), else nullptr
+    const int32_t* like_cols;
+    const double* like_vals;
     const double* c0;          // [DP] centre the moments are taken about
     double target, acc_window, asig, max_up;
     double acc_w, acc_wW;      // acceptance de-weighting: w = 1 - deweight, w*window; acc_w < 0 = off
@@ -427,6 +430,43 @@ __device__ __forceinline__ double loglike_quadform_lds(const double* xq, cptr_f6
     return logl;
 }
 
+// The same sum over the entries of Error that are not zero (rows of Error^T in compressed form, made by the host when
+// the matrix is sparse -- the reference's own TDummy matrix is the identity plus one correlated pair: 52 entries of 2 500
+// at D = 50).  A skipped term is (h * 0) * p[j] = +-0 for finite h and p[j], and `logl -= +-0` leaves logl as it is (logl
+// starts at +0 and x - y is never -0 unless x is): bit for bit the dense sum.  With a non-finite coordinate the skipped
+// terms would be NaN -- but then the diagonal term of that coordinate (the host insists on a full diagonal) makes this
+// sum non-finite too, and the caller falls back on the dense one.
+struct QuadCsr {
+    const int32_t* rowptr;     // [dim + 1], nullptr: no compressed form, use the dense sum
+    const int32_t* cols;       // [nnz] column j of entry k of row i of Error^T (= Error(j, i)), ascending within a row
+    const double* vals;        // [nnz]
+};
+typedef const __attribute__((address_space(4))) int32_t* cptr_i32;
+__device__ __forceinline__ cptr_i32 as_const(const int32_t* p) {
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+    return (cptr_i32)p;
+#pragma clang diagnostic pop
+}
+template <bool EXACT, typename Point>
+__device__ __forceinline__ double quadform_csr(const Point& point, const QuadCsr& q, int D) {
+    const cptr_i32 rp = as_const(q.rowptr), cl = as_const(q.cols);
+    const cptr_f64 vl = as_const(q.vals);
+    double logl = 0.0;
+    int k = rp[0];
+    for (int i = 0; i < D; ++i) {
+        const int kend = rp[i + 1];
+        const double h = 0.5 * point(i);
+        for (; k < kend; ++k) {
+            const double e = vl[k];
+            const double pj = point(cl[k]);
+            if constexpr (EXACT) logl -= h * e * pj;
+            else logl = SMCMC_FMA(-(h * e), pj, logl);
+        }
+    }
+    return logl;
+}
+
 template <int DP, int LIKE, bool EXACT, bool FULLU, bool MOMENTS, bool SPECIAL>
 __global__ void __launch_bounds__(kWave, 2) step_kernel(const StepParams p) {
     constexpr int T = Geo<DP>::T;
@@ -573,7 +613,15 @@ __global__ void __launch_bounds__(kWave, 2) step_kernel(const StepParams p) {
             rms_trials = (p.step_rms_window < rms_trials + 1) ? p.step_rms_window : rms_trials + 1;
             step_rms = __builtin_sqrt(ms);
         }
-        if constexpr (SWAP) logl_prop = loglike_quadform_lds<DP, EXACT>(xcol, likep + p.zero * (s + 1));
+        if constexpr (SWAP) {
+            bool dense = p.like_rowptr == nullptr;
+            if (!dense) {
+                const QuadCsr csr = {p.like_rowptr + p.zero * (s + 1), p.like_cols, p.like_vals};
+                logl_prop = quadform_csr<EXACT>([&](int j) { return xcol[j * kXStride]; }, csr, D);
+                dense = __any(!__builtin_isfinite(logl_prop));
+            }
+            if (dense) logl_prop = loglike_quadform_lds<DP, EXACT>(xcol, likep + p.zero * (s + 1));
+        }
         else logl_prop = loglike<DP, LIKE, EXACT>(xp, likep + p.zero * (s + 1), D);
         bool take;
         if (p.metropolis == 2) {

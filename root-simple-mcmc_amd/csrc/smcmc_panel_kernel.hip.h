@@ -44,6 +44,7 @@ struct PanelParams {
     uint64_t seed;
     const double* Uperm;      // [W][dim][CW]
     const double* like;       // ROSENBROCK: {b}; QUADFORM in reference order: Error^T [dim][dim] (like[i * dim + j] = Error(j, i))
+    QuadCsr like_csr;         // ... and its non-zero entries when it is sparse (quadform_csr), rowptr == nullptr otherwise
     double target, acc_window, asig, max_up, acc_w, acc_wW;
     int per_lane_update, step_rms_window, full_u;
     double* x;                // [dim][npad]
@@ -132,7 +133,7 @@ constexpr bool kLikeFromImage = (LIKE == SMCMC_LIKE_QUADFORM || LIKE == SMCMC_LI
 
 template <int LIKE, bool EXACT>
 __device__ __forceinline__ double serial_loglike(const double* __restrict__ x, int chain, size_t npad, int D,
-                                                 const double* __restrict__ like);
+                                                 const double* __restrict__ like, QuadCsr csr = QuadCsr{nullptr, nullptr, nullptr});
 
 // SPECIAL = the instantiation that also knows uniform per-dimension proposals and the scan of one dimension
 // (kept out of the common kernel: with them in, D=500 went from 0.89 to 2.85 ms/step)
@@ -531,7 +532,7 @@ __global__ void __launch_bounds__(W * kWave) panel_step_kernel(const PanelParams
         if constexpr (LIKE == SMCMC_LIKE_USER || LIKE == SMCMC_LIKE_CONSTRAINED) {
             // one lane per chain walks the proposal's image (complete and visible since the gather's barriers) as the
             // reference's functor walks its vector
-            if (w == 0) lsum = serial_loglike<LIKE, EXACT>(p.scratch, chain, NP, D, p.like);
+            if (w == 0) lsum = serial_loglike<LIKE, EXACT>(p.scratch, chain, NP, D, p.like, p.like_csr);
         }
 
         if constexpr (LIKE == SMCMC_LIKE_HORRIFIC) {
@@ -629,7 +630,7 @@ __global__ void __launch_bounds__(W * kWave) panel_step_kernel(const PanelParams
 // loglike<DP, LIKE, false>; QUADFORM reads Error^T as a plain [D][D] matrix.
 template <int LIKE, bool EXACT>
 __device__ __forceinline__ double serial_loglike(const double* __restrict__ x, int chain, size_t npad, int D,
-                                                 const double* __restrict__ like) {
+                                                 const double* __restrict__ like, QuadCsr csr) {
     double lsum = 0.0;
     if constexpr (LIKE == SMCMC_LIKE_USER) {
 #ifdef SMCMC_USER_LIKELIHOOD_ANY_DIM
@@ -658,7 +659,13 @@ __device__ __forceinline__ double serial_loglike(const double* __restrict__ x, i
             else lsum = SMCMC_FMA(t, pi, lsum);
         }
     } else if constexpr (LIKE == SMCMC_LIKE_QUADFORM) {
-        lsum = quadform_serial<EXACT>(x + chain, npad, as_const(like), D);
+        bool dense = csr.rowptr == nullptr;
+        if (!dense) {
+            const double* pc = x + chain;
+            lsum = quadform_csr<EXACT>([&](int j) { return pc[(size_t)j * npad]; }, csr, D);
+            dense = __any(!__builtin_isfinite(lsum));
+        }
+        if (dense) lsum = quadform_serial<EXACT>(x + chain, npad, as_const(like), D);
     } else if constexpr (LIKE == SMCMC_LIKE_ASYM) {
         for (int i = 0; i < D; ++i) {
             const double pi = x[(size_t)i * npad + chain];

@@ -56,6 +56,7 @@ struct PerChainParams {
     uint32_t chain_offset;
     uint64_t seed;
     const double* like;        // QUADFORM: Error^T [dim][dim]; ROSENBROCK {b}; ...
+    QuadCsr like_csr;          // QUADFORM with a sparse Error: its non-zero entries (quadform_csr), rowptr == nullptr otherwise
     double target, acc_window, asig, max_up;
     double acc_w, acc_wW;      // acceptance de-weighting: w = 1 - deweight, w * window; acc_w < 0 = off
     double cov_w, cov_wW;      // the same for the covariance / centre trials (:1056-1067)
@@ -603,7 +604,12 @@ __global__ void __launch_bounds__(kWave, 1) perchain_step_kernel(const PerChainP
                     for (int q = 0; q < kPcBatch; ++q)
                         if (i0 + q < D) vec[(i0 + q) * kWave] = pv[q];
                 }
-                lp = pc_quadform_lds(vec, as_const(p.like), D);
+                bool dense = p.like_csr.rowptr == nullptr;
+                if (!dense) {
+                    lp = quadform_csr<true>([&](int j) { return vec[j * kWave]; }, p.like_csr, D);
+                    dense = __any(!__builtin_isfinite(lp));
+                }
+                if (dense) lp = pc_quadform_lds(vec, as_const(p.like), D);
             } else {
                 lp = serial_loglike<LIKE, true>(p.proposed, chain, NP, D, p.like);
             }

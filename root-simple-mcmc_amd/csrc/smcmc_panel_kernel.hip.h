@@ -485,7 +485,15 @@ __global__ void __launch_bounds__(W * kWave) panel_step_kernel(const PanelParams
                 const bool summing = (w == 0) && ((lane >> 5) == pass);
                 const double* pl = ulds + (lane & 31);
                 double acc = 0.0;
-                for (int i = 0; i < D; ++i) {
+                // a sparse Error: the summing lanes walk its non-zero entries (quadform_csr: bit for bit the dense sum
+                // unless a coordinate is not finite -- then the whole workgroup takes the dense loop below)
+                bool sparse_done = false;
+                if (p.like_csr.rowptr != nullptr) {
+                    if (summing) acc = quadform_csr<EXACT>([&](int j) { return pl[j * 32]; }, p.like_csr, D);
+                    sparse_done = __syncthreads_or(summing && !__builtin_isfinite(acc)) == 0;
+                    if (!sparse_done) acc = 0.0;
+                }
+                for (int i = 0; i < (sparse_done ? 0 : D); ++i) {
                     // the next row: loaded before the sum (D <= W * kWave: one element per thread), stored after it
                     double enext = 0.0;
                     if (i + 1 < D && (int)threadIdx.x < D) enext = p.like[(size_t)(i + 1) * D + threadIdx.x];

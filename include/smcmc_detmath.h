@@ -372,6 +372,39 @@ SMCMC_HD uint32_t smcmc_normal_angle_index(uint32_t w1) { return (w1 >> 24) & 63
     *n0 = r_ * cs_;                                                                                                     \
     *n1 = r_ * ss_;
 
+/* The same pair with the angle's table spread over the half circle: 128 entries, entry 64 + k = (-sin, cos) of entry k
+ * (the rotation by pi/2), and the other half circle is the sign of both values, i.e. of the radius.  Bit for bit
+ * SMCMC_NORMAL_PAIR_BODY: negation commutes with every rounding in the rotation by delta, so q = 1 gives exactly
+ * (-sn, c), and r * (-v) = -(r * v).  It trades the quadrant's compare, four selects and seven integer operations for
+ * an AND and an XOR; a kernel with room for the 2 KB table uses it (smcmc_kernels.hip.h).  AT2(c) reads component c of
+ * the entry (w1 >> 24) & 127. */
+#define SMCMC_NORMAL_PAIR_BODY_HALFCIRCLE(LT, AT2)                                                                      \
+    const uint64_t ub_ = smcmc_d2u(smcmc_u01(w0));                                                                      \
+    const uint32_t uh_ = (uint32_t)(ub_ >> 32);                                                                         \
+    const int e_ = (int)(uh_ >> 20) - 1023;                                                                             \
+    const uint32_t lk_ = (uh_ >> 14) & 63u;                                                                             \
+    const double m_ = smcmc_u2d((ub_ & 0x000fffffffffffffull) | 0x3ff0000000000000ull);                                 \
+    const double t_ = SMCMC_FMA(m_, LT(lk_, 0), -1.0);                                                                  \
+    double q_ = SMCMC_FMA(t_, 0x1.5555555555555p-2, -0x1.999999999999ap-2);                                             \
+    q_ = SMCMC_FMA(t_, q_, 0.5);                                                                                        \
+    q_ = SMCMC_FMA(t_, q_, -0x1.5555555555555p-1);                                                                      \
+    q_ = SMCMC_FMA(t_, q_, 1.0);                                                                                        \
+    q_ = SMCMC_FMA(t_, q_, -2.0);                                                                                       \
+    const double s_ = SMCMC_FMA(t_, q_, SMCMC_FMA((double)e_, -0x1.62e42fefa39efp+0, LT(lk_, 1)));                      \
+    const double r_ = smcmc_sqrt_mid(s_);                                                                               \
+    const int32_t f_ = (int32_t)(w1 & 0x00ffffffu) - 0x00800000;                                                        \
+    const double d_ = SMCMC_FMA((double)f_, 0x1.921fb54442d18p-30, 0x1.921fb54442d18p-31);                              \
+    const double z_ = d_ * d_;                                                                                          \
+    const double sd_ = SMCMC_FMA(d_ * z_, SMCMC_FMA(z_, 0x1.1111111111111p-7, -0x1.5555555555555p-3), d_);              \
+    const double cd_ = SMCMC_FMA(z_, SMCMC_FMA(z_, SMCMC_FMA(z_, -0x1.6c16c16c16c17p-10, 0x1.5555555555555p-5), -0.5), 1.0); \
+    const double ck_ = AT2(0), sk_ = AT2(1);                                                                            \
+    const double c_ = SMCMC_FMA(-sk_, sd_, ck_ * cd_);                                                                  \
+    const double sn_ = SMCMC_FMA(ck_, sd_, sk_ * cd_);                                                                  \
+    const double rs_ = smcmc_u2d(smcmc_d2u(r_) ^ ((uint64_t)(w1 & 0x80000000u) << 32));                                 \
+    *n0 = rs_ * c_;                                                                                                     \
+    *n1 = rs_ * sn_;
+SMCMC_HD uint32_t smcmc_normal_angle_index_halfcircle(uint32_t w1) { return (w1 >> 24) & 127u; }
+
 static const double smcmc_log_table_host[128] = SMCMC_LOG_TABLE_INIT;
 static const double smcmc_angle_table_host[128] = SMCMC_ANGLE_TABLE_INIT;
 #if defined(__HIPCC__)

@@ -88,6 +88,7 @@ def _declare(L):
     L.oracle_sincos2pi_u32_v.argtypes = [C.c_int, _dp, _dp, _dp]
     L.oracle_u01_v.argtypes = [C.c_int, _dp, _dp]
     L.oracle_normal_pair_v.argtypes = [C.c_int, _dp, _dp, _dp, _dp]
+    L.oracle_normal_pair_halfcircle_v.argtypes = [C.c_int, _dp, _dp, _dp, _dp]
     L.oracle_philox.argtypes = [C.c_uint32] * 6 + [C.POINTER(C.c_uint32)]
     L.oracle_philox_rounds.argtypes = [C.c_uint32] * 6 + [C.c_int, C.c_int, C.POINTER(C.c_uint32)]
     L.oracle_philox_draw_rounds.restype = C.c_int
@@ -443,6 +444,12 @@ def det_u01(w):
 def det_normal_pair(w0, w1):
     w0 = _f64(w0); w1 = _f64(w1); a = np.empty_like(w0); b = np.empty_like(w0)
     lib().oracle_normal_pair_v(w0.size, _p(w0), _p(w1), _p(a), _p(b)); return a, b
+
+
+def det_normal_pair_halfcircle(w0, w1):
+    """SMCMC_NORMAL_PAIR_BODY_HALFCIRCLE (the form the step kernels run) with the table the kernels build."""
+    w0 = _f64(w0); w1 = _f64(w1); a = np.empty_like(w0); b = np.empty_like(w0)
+    lib().oracle_normal_pair_halfcircle_v(w0.size, _p(w0), _p(w1), _p(a), _p(b)); return a, b
 
 
 def philox(ctr, key):

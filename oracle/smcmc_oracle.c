@@ -164,6 +164,33 @@ void oracle_u01_v(int n, const double* w, double* out) { for (int i = 0; i < n; 
 void oracle_normal_pair_v(int n, const double* w0, const double* w1, double* n0, double* n1) {
     for (int i = 0; i < n; ++i) smcmc_normal_pair((uint32_t)w0[i], (uint32_t)w1[i], &n0[i], &n1[i]);
 }
+
+/* The half-circle form of the pair (SMCMC_NORMAL_PAIR_BODY_HALFCIRCLE, what the step kernels run with a 128-entry angle
+ * table in LDS), with the table built the way the kernel builds it: tests/test_detmath.py checks it bit for bit against
+ * smcmc_normal_pair. */
+static void oracle_normal_pair_halfcircle(uint32_t w0, uint32_t w1, double* n0, double* n1) {
+    static double at2[256];
+    static int ready = 0;
+    if (!ready) {
+        for (int k = 0; k < 64; ++k) {
+            const double c = smcmc_angle_table_host[2 * k], sn = smcmc_angle_table_host[2 * k + 1];
+            at2[2 * k] = c;
+            at2[2 * k + 1] = sn;
+            at2[128 + 2 * k] = -sn;
+            at2[128 + 2 * k + 1] = c;
+        }
+        ready = 1;
+    }
+    const uint32_t idx_ = smcmc_normal_angle_index_halfcircle(w1);
+#define ORACLE_LT(k, c) smcmc_log_table_host[2u * (k) + (c)]
+#define ORACLE_AT2(c) at2[2u * idx_ + (c)]
+    SMCMC_NORMAL_PAIR_BODY_HALFCIRCLE(ORACLE_LT, ORACLE_AT2)
+#undef ORACLE_LT
+#undef ORACLE_AT2
+}
+void oracle_normal_pair_halfcircle_v(int n, const double* w0, const double* w1, double* n0, double* n1) {
+    for (int i = 0; i < n; ++i) oracle_normal_pair_halfcircle((uint32_t)w0[i], (uint32_t)w1[i], &n0[i], &n1[i]);
+}
 /* `rounds` rounds starting at round `first` of the key schedule (the engine draws with SMCMC_PHILOX_ROUNDS rounds) */
 void oracle_philox_rounds(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, int first,
                           int rounds, uint32_t* out) {

@@ -75,7 +75,7 @@ constexpr bool kAsmReads = DP >= 47;
 template <bool ASM>
 __device__ __forceinline__ NormalTables normal_tables_fetch(uint32_t w0, uint32_t w1, uint32_t lt_base, uint32_t at_base) {
     NormalTables t;
-    const uint32_t la = lt_base + 16u * smcmc_normal_log_index(w0), aa = at_base + 16u * smcmc_normal_angle_index(w1);
+    const uint32_t la = lt_base + 16u * smcmc_normal_log_index(w0), aa = at_base + 16u * smcmc_normal_angle_index_halfcircle(w1);
     if constexpr (ASM) {
         asm volatile("ds_read_b128 %0, %1" : "=v"(t.le) : "v"(la));
         asm volatile("ds_read_b128 %0, %1" : "=v"(t.ae) : "v"(aa));
@@ -95,8 +95,8 @@ __device__ __forceinline__ void normal_tables_ready(NormalTables& a) {
 }
 __device__ __forceinline__ void normal_pair_lds(uint32_t w0, uint32_t w1, const NormalTables& t, double* n0, double* n1) {
 #define SMCMC_LT_LDS(k, c) (t.le[c])
-#define SMCMC_AT_LDS(k, c) (t.ae[c])
-    SMCMC_NORMAL_PAIR_BODY(SMCMC_LT_LDS, SMCMC_AT_LDS)
+#define SMCMC_AT_LDS(c) (t.ae[c])
+    SMCMC_NORMAL_PAIR_BODY_HALFCIRCLE(SMCMC_LT_LDS, SMCMC_AT_LDS)
 #undef SMCMC_LT_LDS
 #undef SMCMC_AT_LDS
 }
@@ -476,7 +476,7 @@ __global__ void __launch_bounds__(kWave, 2) step_kernel(const StepParams p) {
     typedef ULayout<DP, FULLU> UL;
     __shared__ double xs[ROWS * kXStride];   // accepted point, x[row][lane]
     __shared__ __attribute__((aligned(16))) double us[UL::SIZE];   // decomposition, every lane reads the same word
-    __shared__ __attribute__((aligned(16))) double ntab[256];      // tables of the normal transform: log [64][2], angle [64][2]
+    __shared__ __attribute__((aligned(16))) double ntab[384];      // tables of the normal transform: log [64][2], angle over the half circle [128][2]
 
     const int lane = threadIdx.x;
     const int group = blockIdx.x;
@@ -521,9 +521,14 @@ __global__ void __launch_bounds__(kWave, 2) step_kernel(const StepParams p) {
         }
     }
 
-    for (int k = lane; k < 128; k += kWave) {
-        ntab[k] = smcmc_log_table_dev[k];
-        ntab[128 + k] = smcmc_angle_table_dev[k];
+    for (int k = lane; k < 128; k += kWave) ntab[k] = smcmc_log_table_dev[k];
+    for (int k = lane; k < 64; k += kWave) {
+        // entry 64 + k is entry k turned by pi / 2: (-sin, cos) (SMCMC_NORMAL_PAIR_BODY_HALFCIRCLE)
+        const double c = smcmc_angle_table_dev[2 * k], sn = smcmc_angle_table_dev[2 * k + 1];
+        ntab[128 + 2 * k] = c;
+        ntab[128 + 2 * k + 1] = sn;
+        ntab[128 + 128 + 2 * k] = -sn;
+        ntab[128 + 128 + 2 * k + 1] = c;
     }
     const uint32_t ltab = (uint32_t)(uintptr_t)(lds_cptr_f64)ntab, atab = ltab + 128u * 8u;   // LDS byte addresses
 

@@ -188,3 +188,22 @@ def test_normal_tails_and_moments(oracle):
     r = np.hypot(*oracle.det_normal_pair(ws, np.full(ws.size, 999.0)))
     assert np.all(np.diff(r) < 0)
     assert (r > 6.0).sum() == int(np.floor(2.0 ** 32 * np.exp(-18.0) - 0.5)) + 1
+
+
+def test_halfcircle_form_of_the_pair_is_the_same_function(oracle):
+    """The step kernels run SMCMC_NORMAL_PAIR_BODY_HALFCIRCLE (a 128-entry angle table over the half circle, the other
+    half as the sign of the radius) instead of the quadrant logic of smcmc_normal_pair: the same bits for every word --
+    all 256 table cells with the extreme and random remainders, and random words."""
+    rng = np.random.default_rng(11)
+    cells = np.arange(256, dtype=np.uint64) << np.uint64(24)
+    rests = np.concatenate([[0, 1, 0x7fffff, 0x800000, 0x800001, 0xffffff], rng.integers(0, 1 << 24, 58)]).astype(np.uint64)
+    w1 = (cells[:, None] | rests[None, :]).ravel()
+    w0 = rng.integers(0, 1 << 32, w1.size, dtype=np.uint64)
+    w0[:8] = [0, 1, 2, 0xffffffff, 0xfffffffe, 0x80000000, 0x7fffffff, 0x00010000]
+    more = rng.integers(0, 1 << 32, (2, 200000), dtype=np.uint64)
+    w0 = np.concatenate([w0, more[0]]).astype(np.float64)
+    w1 = np.concatenate([w1, more[1]]).astype(np.float64)
+    a0, a1 = oracle.det_normal_pair(w0, w1)
+    b0, b1 = oracle.det_normal_pair_halfcircle(w0, w1)
+    assert np.array_equal(a0.view(np.uint64), b0.view(np.uint64))
+    assert np.array_equal(a1.view(np.uint64), b1.view(np.uint64))

@@ -810,14 +810,18 @@ __global__ void __launch_bounds__(kWave, 2) step_kernel(const StepParams p) {
                     }
                 }
                 if constexpr (MOMENTS) {
-                    // The group's second moments: the 16 x NT matrix instructions of the 64-chain
-                    // contraction are dealt out over the pieces of the step (1-2 per piece), so
-                    // each one runs on the matrix pipe under the piece's VALU work instead of
-                    // stalling the wavefront back to back.  Chains fold in ascending order.
+                    // The group's second moments: the 16 x NT matrix instructions of the 64-chain contraction are
+                    // dealt out over the pieces of the step (1-2 per piece) and pinned BEHIND the piece's vector work.
+                    // An FP64 matrix instruction holds the vector pipe for its 64 cycles but not the issue of LDS
+                    // reads, waits and scalar instructions: what follows it here is exactly that -- the prefetched
+                    // operands of the next k-quad, then the next piece's eight reads and its wait -- and runs in
+                    // its shadow.  (Left to the scheduler it goes to the top of the piece, in front of 32 vector
+                    // instructions that then wait for it.)  Chains fold in ascending order.
                     constexpr int g = PC::first_global() + r;          // piece number within the step
                     constexpr int G = UPieces<DP, FULLU, NB - 1>::first_global() + UPieces<DP, FULLU, NB - 1>::COUNT;
                     constexpr int NM = 16 * NT;
                     constexpr int m_lo = (int)(((long)g * NM) / G), m_hi = (int)(((long)(g + 1) * NM) / G);
+                    if constexpr (m_hi > m_lo) __builtin_amdgcn_sched_barrier(0);
                     static_for<m_hi - m_lo>([&](auto mc) {
                         constexpr int m = m_lo + decltype(mc)::value;
                         constexpr int kk = m / NT, tile = m % NT;
@@ -834,12 +838,6 @@ __global__ void __launch_bounds__(kWave, 2) step_kernel(const StepParams p) {
                                 else ms = xs[xsrow + 4 * kk] - c0s;
                                 ms = (16 * Geo<DP>::T16 + (lane & 3) <= DP) ? ms : 0.0;
                             }
-                            if constexpr (OPF && kk + 1 < 16) {
-                                // the next k-quad's first matrix instruction sits in a later piece
-                                static_assert(((long)(kk + 1) * NT * G) / NM > g, "operand prefetch needs a piece boundary");
-                                fetch_operands<T, kk + 1>(xaddr, raw);
-                                if constexpr (STRIP) fetch_operand<kk + 1>(xsaddr, raws);
-                            }
                         }
                         if constexpr (!STRIP || tile < NT16) {
                             constexpr int ti = tile_row(tile), tj = tile - ti * (ti + 1) / 2;
@@ -851,6 +849,13 @@ __global__ void __launch_bounds__(kWave, 2) step_kernel(const StepParams p) {
                             constexpr int t = tile - NT16;
                             accs[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(ms, ma[t], accs[t], 0, 0, 0);
                             asm volatile("" : "+a"(accs[t]));
+                        }
+                        if constexpr (tile == 0 && OPF && kk + 1 < 16) {
+                            // (behind the k-quad's first matrix instruction: in its shadow) the next k-quad's first
+                            // matrix instruction sits in a later piece
+                            static_assert(((long)(kk + 1) * NT * G) / NM > g, "operand prefetch needs a piece boundary");
+                            fetch_operands<T, kk + 1>(xaddr, raw);
+                            if constexpr (STRIP) fetch_operand<kk + 1>(xsaddr, raws);
                         }
                     });
                 }

@@ -437,7 +437,8 @@ def main():
                      "fp64_TFLOPs": fp64_tflops, "fp64_issue_frac": fp64_tflops / FP64_PEAK_TFLOPS,
                      "fp64_model": "flops of SURVEY.md 8d (2 D^2 + 3 D) per chain-step / kernel time / 78.6 TFLOP/s",
                      "measured_bound": "instruction issue: one wavefront per SIMD pays ~4 cycles per instruction of any kind and 64 per "
-                                       "FP64 matrix instruction, nothing overlaps them (profiles/r03_notes.md, tools/micro/pipe_overlap.hip)",
+                                       "FP64 matrix instruction; only LDS reads, waits and scalar instructions issue in a matrix "
+                                       "instruction's shadow (profiles/r03_notes.md, tools/micro/pipe_overlap.hip)",
                      "limiter": "instruction issue of a lone wavefront per SIMD; see profiles/r03_notes.md",
                      "algorithmic_bytes_per_launch": per_launch * bytes_cs,
                      "kernel": "step_kernel<%d,%s,%s,tri,moments>" % (dim, "QUADFORM" if args.header_tdummy else "ISO",

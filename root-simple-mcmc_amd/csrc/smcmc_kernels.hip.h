@@ -566,10 +566,11 @@ __global__ void __launch_bounds__(kWave, 2) step_kernel(const StepParams p) {
     __syncthreads();
 
     // operand prefetch of the fold (fetch_operands): only where a k-quad's matrix instructions span several pieces, only
-    // with the other hand-placed reads (kAsmReads), and only in the common kernels (triangular decomposition, no
-    // uniform dimensions / scan): in the 63-dimension family the others are short of registers and the compiler
-    // spilled the prefetched operands behind their reads (found by the build's listing check)
-    constexpr bool OPF = MOMENTS && T >= 3 && kAsmReads<DP> && !FULLU && !SPECIAL;
+    // with the other hand-placed reads (kAsmReads), only in the common kernels (triangular decomposition, no uniform
+    // dimensions / scan) and not in the 63-dimension family: there the kernels are short of registers and the compiler
+    // spilled the prefetched operands behind their reads in one variant or another (the build's listing check
+    // refused them)
+    constexpr bool OPF = MOMENTS && T >= 3 && kAsmReads<DP> && DP <= 50 && !FULLU && !SPECIAL;
     double raw[OPF ? T : 1], raws = 0.0;
     uint32_t xaddr[OPF ? T : 1], xsaddr = 0;
     if constexpr (OPF) {
@@ -754,6 +755,20 @@ __global__ void __launch_bounds__(kWave, 2) step_kernel(const StepParams p) {
         asm volatile("" : "+v"(up));
         double ma[MOMENTS ? T : 1];   // matrix-pipe operands of the chain quad being folded
         double ms = 0.0;              // ... and the strip rows' operand
+        // The Philox block and the table entries of the NEXT block of four normals are made during the last piece of the
+        // current one (kAsmReads: the table reads then have a whole piece to come back in, and sit in the registers the
+        // idle `nxt` buffer leaves free); two sets in turn, indexed at compile time -- never copied while in flight.
+        constexpr bool PIPE = kAsmReads<DP>;
+        smcmc_u32x4 blks[2];
+        NormalTables tabs[2][2];
+        auto draw_and_fetch = [&](auto bn) {
+            constexpr int b1 = decltype(bn)::value;
+            blks[b1 & 1] = smcmc_draw_block(p.seed, gid, step, (uint32_t)b1, SMCMC_STREAM_STEP);
+            tabs[b1 & 1][0] = normal_tables_fetch<kAsmReads<DP>>(blks[b1 & 1].v[0], blks[b1 & 1].v[1], ltab, atab);
+            if constexpr (4 * b1 + 2 < DP)
+                tabs[b1 & 1][1] = normal_tables_fetch<kAsmReads<DP>>(blks[b1 & 1].v[2], blks[b1 & 1].v[3], ltab, atab);
+        };
+        if constexpr (PIPE) draw_and_fetch(std::integral_constant<int, 0>{});
         static_for<NB>([&](auto bc) {
             constexpr int b = decltype(bc)::value;
             // U rows 4b..4b+3 are consumed in pieces of kPiece columns; the LDS reads of a
@@ -763,13 +778,14 @@ __global__ void __launch_bounds__(kWave, 2) step_kernel(const StepParams p) {
             typedef UPieces<DP, FULLU, b> PC;
             f64x2 cur[kPiece / 2], nxt[kPiece / 2];
 
-            smcmc_u32x4 blk = smcmc_draw_block(p.seed, gid, step, (uint32_t)b, SMCMC_STREAM_STEP);
+            if constexpr (!PIPE) draw_and_fetch(bc);
+            smcmc_u32x4& blk = blks[b & 1];
             if ((uint32_t)b == (aw >> 2)) uword = smcmc_select_word(blk, aw & 3u);
             // LDS reads of the block, in this order (they return in issue order): the table entries of its two pairs of
-            // normals, then the first piece of U, which stays in flight under the normals' arithmetic
-            NormalTables t0 = normal_tables_fetch<kAsmReads<DP>>(blk.v[0], blk.v[1], ltab, atab);
-            NormalTables t1;   // (never a copy of t0: a copy of registers whose read is still in flight copies what was there before)
-            if constexpr (4 * b + 2 < DP) t1 = normal_tables_fetch<kAsmReads<DP>>(blk.v[2], blk.v[3], ltab, atab);
+            // normals (issued here, or during the last piece of the block before), then the first piece of U, which
+            // stays in flight under the normals' arithmetic
+            NormalTables& t0 = tabs[b & 1][0];
+            NormalTables& t1 = tabs[b & 1][1];
             {
                 constexpr int i0 = PC::row(0), c0p = PC::col(0);
                 load_piece<DP, FULLU, i0, c0p>(up, cur);
@@ -794,6 +810,8 @@ __global__ void __launch_bounds__(kWave, 2) step_kernel(const StepParams p) {
                     piece_ready<piece_reads<DP, FULLU, c1>(), piece_reads<DP, FULLU, c>(), kAsmReads<DP>>(cur);
                 } else {
                     piece_ready<0, piece_reads<DP, FULLU, c>(), kAsmReads<DP>>(cur);
+                    // the last piece of the block: the next block's random words and its table reads
+                    if constexpr (PIPE && b + 1 < NB) draw_and_fetch(std::integral_constant<int, b + 1>{});
                 }
                 const double srow = sr[i - 4 * b];
 #pragma unroll

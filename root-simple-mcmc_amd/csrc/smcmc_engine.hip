@@ -100,6 +100,7 @@ struct smcmc_engine {
     // QUADFORM with a sparse Error matrix: the non-zero entries of Error^T, row by row (quadform_csr); nullptr = dense only
     int32_t* d_like_rowptr = nullptr;
     int32_t* d_like_cols = nullptr;
+    int32_t* d_like_rows = nullptr;
     double* d_like_vals = nullptr;
     int like_nnz = 0;
     bool dense_quadform = false;   // SMCMC_P_DENSE_QUADFORM
@@ -303,30 +304,33 @@ int upload_shared(smcmc_engine* h) {
 // matrix is finite, has a full diagonal (so that a non-finite coordinate always shows in the sparse sum, which then
 // falls back on the dense one) and at most a quarter of its entries are non-zero.
 int upload_like_csr(smcmc_engine* h) {
-    (void)hipFree(h->d_like_rowptr); (void)hipFree(h->d_like_cols); (void)hipFree(h->d_like_vals);
-    h->d_like_rowptr = nullptr; h->d_like_cols = nullptr; h->d_like_vals = nullptr; h->like_nnz = 0;
+    (void)hipFree(h->d_like_rowptr); (void)hipFree(h->d_like_cols); (void)hipFree(h->d_like_vals); (void)hipFree(h->d_like_rows);
+    h->d_like_rowptr = nullptr; h->d_like_cols = nullptr; h->d_like_vals = nullptr; h->d_like_rows = nullptr; h->like_nnz = 0;
     if (h->likelihood != SMCMC_LIKE_QUADFORM || h->dense_quadform) return SMCMC_OK;
     const int D = h->dim;
-    std::vector<int32_t> rowptr(D + 1, 0), cols;
+    std::vector<int32_t> rows, cols;
     std::vector<double> vals;
     for (int i = 0; i < D; ++i) {
         for (int j = 0; j < D; ++j) {
             const double e = h->like_params[(size_t)j * D + i];                  // Error(j, i) = Error^T(i, j)
             if (!std::isfinite(e)) return SMCMC_OK;
             if (i == j && e == 0.0) return SMCMC_OK;
-            if (e != 0.0) { cols.push_back(j); vals.push_back(e); }
+            if (e != 0.0) { rows.push_back(i); cols.push_back(j); vals.push_back(e); }
         }
-        rowptr[i + 1] = (int32_t)cols.size();
     }
     if (cols.size() * 4 > (size_t)D * D) return SMCMC_OK;
-    HIP_TRY(h, hipMalloc(&h->d_like_rowptr, sizeof(int32_t) * rowptr.size()));
+    h->like_nnz = (int)cols.size();
+    while (cols.size() % smcmc::kQuadChunk != 0) { rows.push_back(0); cols.push_back(0); vals.push_back(0.0); }   // zero entries: skipped terms
+    const int32_t padded = (int32_t)cols.size();
+    HIP_TRY(h, hipMalloc(&h->d_like_rowptr, sizeof(int32_t)));
+    HIP_TRY(h, hipMalloc(&h->d_like_rows, sizeof(int32_t) * rows.size()));
     HIP_TRY(h, hipMalloc(&h->d_like_cols, sizeof(int32_t) * cols.size()));
     HIP_TRY(h, hipMalloc(&h->d_like_vals, sizeof(double) * vals.size()));
-    HIP_TRY(h, hipMemcpyAsync(h->d_like_rowptr, rowptr.data(), sizeof(int32_t) * rowptr.size(), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_like_rowptr, &padded, sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_like_rows, rows.data(), sizeof(int32_t) * rows.size(), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->d_like_cols, cols.data(), sizeof(int32_t) * cols.size(), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->d_like_vals, vals.data(), sizeof(double) * vals.size(), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    h->like_nnz = (int)cols.size();
     return SMCMC_OK;
 }
 
@@ -823,7 +827,7 @@ PerChainParams pc_params(smcmc_engine* h, const StepParams& p) {
     q.nchains = p.nchains; q.npad = p.npad; q.dim = p.dim; q.metropolis = p.metropolis;
     q.step0 = h->total_steps; q.target_step = h->total_steps + (uint32_t)p.nsteps;
     q.chain_offset = p.chain_offset; q.seed = p.seed; q.like = h->d_like;
-    q.like_csr = QuadCsr{h->d_like_rowptr, h->d_like_cols, h->d_like_vals};
+    q.like_csr = QuadCsr{h->d_like_rowptr, h->d_like_cols, h->d_like_vals, h->d_like_rows};
     q.target = p.target; q.acc_window = p.acc_window; q.asig = p.asig; q.max_up = p.max_up;
     pc_deweights(P, q.acc_w, q.acc_wW, q.cov_w, q.cov_wW);
     q.cov_window = P.covWindow; q.cov_frozen = h->pc_frozen ? 1 : 0;
@@ -880,7 +884,7 @@ StepParams make_params(smcmc_engine* h, int nsteps, int metropolis) {
     p.chain_offset = h->chain_offset;
     p.seed = h->seed;
     p.U = h->d_U; p.like = h->d_like; p.c0 = h->d_c0;
-    p.like_rowptr = h->d_like_rowptr; p.like_cols = h->d_like_cols; p.like_vals = h->d_like_vals;
+    p.like_rowptr = h->d_like_rowptr; p.like_cols = h->d_like_cols; p.like_vals = h->d_like_vals; p.like_rows = h->d_like_rows;
     p.target = P.target;
     p.acc_window = P.acceptanceWindow;
     double asig = P.target * (1.0 - P.target);              // TSimpleMCMC.H:1746-1747
@@ -962,7 +966,7 @@ int launch(smcmc_engine* h, int nsteps, int metropolis, int stride, double* save
         q.nchains = p.nchains; q.npad = p.npad; q.dim = p.dim; q.metropolis = p.metropolis;
         q.chain_offset = p.chain_offset; q.seed = p.seed;
         q.Uperm = h->d_U; q.like = h->d_like;
-        q.like_csr = QuadCsr{h->d_like_rowptr, h->d_like_cols, h->d_like_vals};
+        q.like_csr = QuadCsr{h->d_like_rowptr, h->d_like_cols, h->d_like_vals, h->d_like_rows};
         q.target = p.target; q.acc_window = p.acc_window; q.asig = p.asig; q.max_up = p.max_up;
         q.acc_w = p.acc_w; q.acc_wW = p.acc_wW; q.per_lane_update = p.per_lane_update;
         q.step_rms_window = p.step_rms_window; q.full_u = h->prop->decompFull ? 1 : 0;
@@ -1181,7 +1185,7 @@ int smcmc_destroy(smcmc_engine* h) {
     ON_DEVICE(h);
     if (h->d_x) (void)hipStreamSynchronize(h->stream);
     (void)hipFree(h->d_x); (void)hipFree(h->d_forced); (void)hipFree(h->d_proposed); (void)hipFree(h->d_scratch); (void)hipFree(h->d_uniform); (void)hipFree(h->d_lane_f64); (void)hipFree(h->d_lane_i32);
-    (void)hipFree(h->d_U); (void)hipFree(h->d_Uop); (void)hipFree(h->d_like); (void)hipFree(h->d_like_rowptr); (void)hipFree(h->d_like_cols); (void)hipFree(h->d_like_vals); (void)hipFree(h->d_c0); (void)hipFree(h->d_gacc);
+    (void)hipFree(h->d_U); (void)hipFree(h->d_Uop); (void)hipFree(h->d_like); (void)hipFree(h->d_like_rowptr); (void)hipFree(h->d_like_cols); (void)hipFree(h->d_like_vals); (void)hipFree(h->d_like_rows); (void)hipFree(h->d_c0); (void)hipFree(h->d_gacc);
     (void)hipFree(h->d_moments); (void)hipFree(h->d_chunks); (void)hipHostFree(h->h_moments);
     (void)hipFree(h->d_centre); (void)hipFree(h->d_cov); (void)hipFree(h->d_decomp); (void)hipFree(h->d_scal);
     (void)hipFree(h->d_ring); (void)hipFree(h->d_ring_logl);

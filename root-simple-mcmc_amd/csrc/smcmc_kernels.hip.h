@@ -261,6 +261,7 @@ struct StepParams {
     const int32_t* like_rowptr;   // QUADFORM with a sparse Error: its non-zero entries (QuadCsr below), else nullptr
     const int32_t* like_cols;
     const double* like_vals;
+    const int32_t* like_rows;
     const double* c0;          // [DP] centre the moments are taken about
     double target, acc_window, asig, max_up;
     double acc_w, acc_wW;      // acceptance de-weighting: w = 1 - deweight, w*window; acc_w < 0 = off
@@ -437,10 +438,13 @@ __device__ __forceinline__ double loglike_quadform_lds(const double* xq, cptr_f6
 // terms would be NaN -- but then the diagonal term of that coordinate (the host insists on a full diagonal) makes this
 // sum non-finite too, and the caller falls back on the dense one.
 struct QuadCsr {
-    const int32_t* rowptr;     // [dim + 1], nullptr: no compressed form, use the dense sum
-    const int32_t* cols;       // [nnz] column j of entry k of row i of Error^T (= Error(j, i)), ascending within a row
+    const int32_t* rowptr;     // nullptr: no compressed form, use the dense sum; else rowptr[0] = number of entries, padded to
+                               // a multiple of kQuadChunk with zero entries (a zero entry is a skipped term: +-0)
+    const int32_t* cols;       // [nnz] column j of entry k (Error^T(i, j) = Error(j, i)); entries row by row, j ascending
     const double* vals;        // [nnz]
+    const int32_t* rows;       // [nnz] row i of entry k
 };
+constexpr int kQuadChunk = 8;  // entries fetched together: three scalar loads per chunk instead of three dependent ones per entry
 typedef const __attribute__((address_space(4))) int32_t* cptr_i32;
 __device__ __forceinline__ cptr_i32 as_const(const int32_t* p) {
 #pragma clang diagnostic push
@@ -450,20 +454,32 @@ __device__ __forceinline__ cptr_i32 as_const(const int32_t* p) {
 }
 template <bool EXACT, typename Point>
 __device__ __forceinline__ double quadform_csr(const Point& point, const QuadCsr& q, int D) {
-    const cptr_i32 rp = as_const(q.rowptr), cl = as_const(q.cols);
+    const cptr_i32 rw = as_const(q.rows), cl = as_const(q.cols);
     const cptr_f64 vl = as_const(q.vals);
+    const int nnz = as_const(q.rowptr)[0];
     double logl = 0.0;
-    int k = rp[0];
-    for (int i = 0; i < D; ++i) {
-        const int kend = rp[i + 1];
-        const double h = 0.5 * point(i);
-        for (; k < kend; ++k) {
-            const double e = vl[k];
-            const double pj = point(cl[k]);
-            if constexpr (EXACT) logl -= h * e * pj;
-            else logl = SMCMC_FMA(-(h * e), pj, logl);
+    for (int k0 = 0; k0 < nnz; k0 += kQuadChunk) {
+        int ri[kQuadChunk], ci[kQuadChunk];
+        double e[kQuadChunk], pi[kQuadChunk], pj[kQuadChunk];
+#pragma unroll
+        for (int u = 0; u < kQuadChunk; ++u) {
+            ri[u] = rw[k0 + u];
+            ci[u] = cl[k0 + u];
+            e[u] = vl[k0 + u];
+        }
+#pragma unroll
+        for (int u = 0; u < kQuadChunk; ++u) {
+            pi[u] = point(ri[u]);
+            pj[u] = point(ci[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < kQuadChunk; ++u) {
+            const double h = 0.5 * pi[u];
+            if constexpr (EXACT) logl -= h * e[u] * pj[u];
+            else logl = SMCMC_FMA(-(h * e[u]), pj[u], logl);
         }
     }
+    (void)D;
     return logl;
 }
 
@@ -622,7 +638,7 @@ __global__ void __launch_bounds__(kWave, 2) step_kernel(const StepParams p) {
         if constexpr (SWAP) {
             bool dense = p.like_rowptr == nullptr;
             if (!dense) {
-                const QuadCsr csr = {p.like_rowptr + p.zero * (s + 1), p.like_cols, p.like_vals};
+                const QuadCsr csr = {p.like_rowptr + p.zero * (s + 1), p.like_cols, p.like_vals, p.like_rows};
                 logl_prop = quadform_csr<EXACT>([&](int j) { return xcol[j * kXStride]; }, csr, D);
                 dense = __any(!__builtin_isfinite(logl_prop));
             }

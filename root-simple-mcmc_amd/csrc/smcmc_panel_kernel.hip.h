@@ -133,7 +133,7 @@ constexpr bool kLikeFromImage = (LIKE == SMCMC_LIKE_QUADFORM || LIKE == SMCMC_LI
 
 template <int LIKE, bool EXACT>
 __device__ __forceinline__ double serial_loglike(const double* __restrict__ x, int chain, size_t npad, int D,
-                                                 const double* __restrict__ like, QuadCsr csr = QuadCsr{nullptr, nullptr, nullptr});
+                                                 const double* __restrict__ like, QuadCsr csr = QuadCsr{nullptr, nullptr, nullptr, nullptr});
 
 // SPECIAL = the instantiation that also knows uniform per-dimension proposals and the scan of one dimension
 // (kept out of the common kernel: with them in, D=500 went from 0.89 to 2.85 ms/step)

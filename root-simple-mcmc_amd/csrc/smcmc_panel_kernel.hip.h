@@ -135,6 +135,68 @@ template <int LIKE, bool EXACT>
 __device__ __forceinline__ double serial_loglike(const double* __restrict__ x, int chain, size_t npad, int D,
                                                  const double* __restrict__ like, QuadCsr csr = QuadCsr{nullptr, nullptr, nullptr, nullptr});
 
+// The dense D^2-term sum of the header-form TDummy for the chains of one pass (see the call in panel_step_kernel): rows
+// of Error^T staged through LDS by the whole workgroup one row ahead (rbuf holds two rows, row 0 is there on entry), the
+// summing lanes walk pl[j * 32].  Every thread of the workgroup calls it (barriers inside).
+typedef __attribute__((address_space(3))) double* lds_ptr_f64;
+template <int W, int CW>
+__device__ __forceinline__ double panel_quadform_dense_body(const double* __restrict__ like, double* rbuf_generic,
+                                                            const double* pl_generic, int D, bool summing) {
+    constexpr int kERow = W * CW;
+    const lds_ptr_f64 rbuf = (lds_ptr_f64)rbuf_generic;
+    const lds_cptr_f64 pl = (lds_cptr_f64)pl_generic;
+    double acc = 0.0;
+    for (int i = 0; i < D; ++i) {
+        // the next row: loaded before the sum (D <= W * kWave: one element per thread), stored after it
+        double enext = 0.0;
+        if (i + 1 < D && (int)threadIdx.x < D) enext = like[(size_t)(i + 1) * D + threadIdx.x];
+        if (summing) {
+            const double h = 0.5 * pl[i * 32];
+            const lds_cptr_f64 er = rbuf + (i & 1) * kERow;
+            // the LDS reads of a group of kQfLds terms are all issued before its arithmetic, the next group's
+            // before this group's arithmetic (two register sets): the scheduler, left alone, pairs every read
+            // with its use and the sum crawls at one LDS latency per two terms
+            constexpr int G = kQfLds;
+            const int ngr = D / G;
+            double pa[G], pb[G];
+            f64x2 ea[G / 2], eb[G / 2];
+            auto fetch = [&](int j0, double (&pv)[G], f64x2 (&ev)[G / 2]) {
+#pragma unroll
+                for (int u = 0; u < G; ++u) pv[u] = pl[(j0 + u) * 32];
+#pragma unroll
+                for (int u = 0; u < G / 2; ++u) ev[u] = *(lds_cptr_f64x2)(er + j0 + 2 * u);
+            };
+            auto fold = [&](const double (&pv)[G], const f64x2 (&ev)[G / 2]) {
+#pragma unroll
+                for (int u = 0; u < G; ++u) acc -= h * ev[u / 2][u & 1] * pv[u];
+            };
+            if (ngr > 0) fetch(0, pa, ea);
+            for (int g = 0; g < ngr; g += 2) {
+                if (g + 1 < ngr) fetch((g + 1) * G, pb, eb);
+                __builtin_amdgcn_sched_barrier(0);
+                fold(pa, ea);
+                __builtin_amdgcn_sched_barrier(0);
+                if (g + 2 < ngr) fetch((g + 2) * G, pa, ea);
+                __builtin_amdgcn_sched_barrier(0);
+                if (g + 1 < ngr) fold(pb, eb);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            for (int j = ngr * G; j < D; ++j) acc -= h * er[j] * pl[j * 32];
+        }
+        if (i + 1 < D && (int)threadIdx.x < D) rbuf[((i + 1) & 1) * kERow + threadIdx.x] = enext;
+        __syncthreads();
+    }
+    return acc;
+}
+// Out of line in the eight-wavefront kernel: compiled into it, the two register sets of sixteen terms cost that kernel
+// (256 registers per lane) 4 KB of scratch per lane whether the loop runs or not -- 3.6 -> 0.64 ms/step at D = 500 with
+// the sparse walk, 11.7 -> 9.7 with this loop itself.  The four-wavefront kernel has the registers and keeps its copy of
+// the loop inline in the kernel.
+template <int W, int CW>
+__device__ __attribute__((noinline)) double panel_quadform_dense_call(const double* __restrict__ like, double* rbuf,
+                                                                      const double* pl, int D, bool summing) {
+    return panel_quadform_dense_body<W, CW>(like, rbuf, pl, D, summing);
+}
 // SPECIAL = the instantiation that also knows uniform per-dimension proposals and the scan of one dimension
 // (kept out of the common kernel: with them in, D=500 went from 0.89 to 2.85 ms/step)
 template <int W, int CW, int LIKE, bool EXACT, bool SPECIAL>
@@ -474,7 +536,6 @@ __global__ void __launch_bounds__(W * kWave) panel_step_kernel(const PanelParams
             // scalar-cache miss every eight terms.
             static_assert(W * kPanelRows * CW >= W * CW * 32, "the LDS image of 32 chains must fit the U staging area");
             static_assert(kPanelRows * kWave >= 2 * W * CW, "two rows of Error must fit the normals' buffer");
-            constexpr int kERow = W * CW;   // doubles per staged row (>= D)
             for (int pass = 0; pass < 2; ++pass) {
                 __syncthreads();
                 if ((lane >> 5) == pass) {
@@ -493,45 +554,51 @@ __global__ void __launch_bounds__(W * kWave) panel_step_kernel(const PanelParams
                     sparse_done = __syncthreads_or(summing && !__builtin_isfinite(acc)) == 0;
                     if (!sparse_done) acc = 0.0;
                 }
-                for (int i = 0; i < (sparse_done ? 0 : D); ++i) {
-                    // the next row: loaded before the sum (D <= W * kWave: one element per thread), stored after it
-                    double enext = 0.0;
-                    if (i + 1 < D && (int)threadIdx.x < D) enext = p.like[(size_t)(i + 1) * D + threadIdx.x];
-                    if (summing) {
-                        const double h = 0.5 * pl[i * 32];
-                        const double* er = rbuf + (i & 1) * kERow;
-                        // the LDS reads of a group of kQfLds terms are all issued before its arithmetic, the next group's
-                        // before this group's arithmetic (two register sets): the scheduler, left alone, pairs every read
-                        // with its use and the sum crawls at one LDS latency per two terms
-                        constexpr int G = kQfLds;
-                        const int ngr = D / G;
-                        double pa[G], pb[G];
-                        f64x2 ea[G / 2], eb[G / 2];
-                        auto fetch = [&](int j0, double (&pv)[G], f64x2 (&ev)[G / 2]) {
+                if constexpr (W >= 8) {
+                    // out of line in the eight-wavefront kernel (panel_quadform_dense_call)
+                    if (!sparse_done) acc = panel_quadform_dense_call<W, CW>(p.like, rbuf, ulds + (lane & 31), D, summing);
+                } else {
+                    constexpr int kERow = W * CW;   // doubles per staged row (>= D)
+                    for (int i = 0; i < (sparse_done ? 0 : D); ++i) {
+                        // the next row: loaded before the sum (D <= W * kWave: one element per thread), stored after it
+                        double enext = 0.0;
+                        if (i + 1 < D && (int)threadIdx.x < D) enext = p.like[(size_t)(i + 1) * D + threadIdx.x];
+                        if (summing) {
+                            const double h = 0.5 * pl[i * 32];
+                            const double* er = rbuf + (i & 1) * kERow;
+                            // the LDS reads of a group of kQfLds terms are all issued before its arithmetic, the next group's
+                            // before this group's arithmetic (two register sets): the scheduler, left alone, pairs every read
+                            // with its use and the sum crawls at one LDS latency per two terms
+                            constexpr int G = kQfLds;
+                            const int ngr = D / G;
+                            double pa[G], pb[G];
+                            f64x2 ea[G / 2], eb[G / 2];
+                            auto fetch = [&](int j0, double (&pv)[G], f64x2 (&ev)[G / 2]) {
 #pragma unroll
-                            for (int u = 0; u < G; ++u) pv[u] = pl[(j0 + u) * 32];
+                                for (int u = 0; u < G; ++u) pv[u] = pl[(j0 + u) * 32];
 #pragma unroll
-                            for (int u = 0; u < G / 2; ++u) ev[u] = *(const f64x2*)(er + j0 + 2 * u);
-                        };
-                        auto fold = [&](const double (&pv)[G], const f64x2 (&ev)[G / 2]) {
+                                for (int u = 0; u < G / 2; ++u) ev[u] = *(const f64x2*)(er + j0 + 2 * u);
+                            };
+                            auto fold = [&](const double (&pv)[G], const f64x2 (&ev)[G / 2]) {
 #pragma unroll
-                            for (int u = 0; u < G; ++u) acc -= h * ev[u / 2][u & 1] * pv[u];
-                        };
-                        if (ngr > 0) fetch(0, pa, ea);
-                        for (int g = 0; g < ngr; g += 2) {
-                            if (g + 1 < ngr) fetch((g + 1) * G, pb, eb);
-                            __builtin_amdgcn_sched_barrier(0);
-                            fold(pa, ea);
-                            __builtin_amdgcn_sched_barrier(0);
-                            if (g + 2 < ngr) fetch((g + 2) * G, pa, ea);
-                            __builtin_amdgcn_sched_barrier(0);
-                            if (g + 1 < ngr) fold(pb, eb);
-                            __builtin_amdgcn_sched_barrier(0);
+                                for (int u = 0; u < G; ++u) acc -= h * ev[u / 2][u & 1] * pv[u];
+                            };
+                            if (ngr > 0) fetch(0, pa, ea);
+                            for (int g = 0; g < ngr; g += 2) {
+                                if (g + 1 < ngr) fetch((g + 1) * G, pb, eb);
+                                __builtin_amdgcn_sched_barrier(0);
+                                fold(pa, ea);
+                                __builtin_amdgcn_sched_barrier(0);
+                                if (g + 2 < ngr) fetch((g + 2) * G, pa, ea);
+                                __builtin_amdgcn_sched_barrier(0);
+                                if (g + 1 < ngr) fold(pb, eb);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                            for (int j = ngr * G; j < D; ++j) acc -= h * er[j] * pl[j * 32];
                         }
-                        for (int j = ngr * G; j < D; ++j) acc -= h * er[j] * pl[j * 32];
+                        if (i + 1 < D && (int)threadIdx.x < D) rbuf[((i + 1) & 1) * kERow + threadIdx.x] = enext;
+                        __syncthreads();
                     }
-                    if (i + 1 < D && (int)threadIdx.x < D) rbuf[((i + 1) & 1) * kERow + threadIdx.x] = enext;
-                    __syncthreads();
                 }
                 if (summing) lsum = acc;
             }

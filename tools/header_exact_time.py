@@ -1,7 +1,17 @@
-import sys, time, numpy as np
-sys.path.insert(0, '/root/repo')
-import torch
-from smcmc_amd_loader import load_package
+"""Diagnostic (GPU box): ms per ensemble step of the header-form TDummyLogLikelihood (quadratic form, the reference's own
+Error matrix) in the reference's order, frozen covariance, 16 384 chains, D = 64 ... 500 -- with the sparse walk of the
+non-zero entries (default) and with the dense D^2-term sum (SMCMC_P_DENSE_QUADFORM = 1).
+usage: python tools/header_exact_time.py"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+from smcmc_amd_loader import load_package  # noqa: E402
+
 pkg = load_package()
 def err(dim):
     cov = np.eye(dim); cov[0, dim-1] = cov[dim-1, 0] = 0.999999

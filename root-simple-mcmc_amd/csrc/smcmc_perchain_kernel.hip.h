@@ -257,7 +257,9 @@ __global__ void __launch_bounds__(kWave, 1) perchain_step_kernel(const PerChainP
     if (p.update_only) {
         update_proposal(active, load_trace());
     } else {
-        bool live = active && status == kPcOk && tstep < p.target_step;
+        // a resumed chain still owes the rest of the step its UpdateProposal interrupted -- also when that step was the
+        // last one of its launch (tstep already stands at the target then; the loop's end test stops it afterwards)
+        bool live = active && status == kPcOk && (resume || tstep < p.target_step);
         while (__any(live)) {
             if (live && !resume) ++tstep;                               // ++fTotalSteps, :376
             const uint64_t step = (uint64_t)tstep;

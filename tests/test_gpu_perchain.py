@@ -224,6 +224,31 @@ def test_the_fallback_ladder_inside_a_launch(gpu, oracle):
     _same(e, chains, "and on")
 
 
+def test_the_fallback_ladder_on_the_last_step_of_a_launch(gpu, oracle):
+    """The same ladder driven one step per launch (what TSimpleMCMC_amd.H::Step() does for a single chain): every ladder
+    event then lands on the LAST step of its launch, the chain stops with its step counter already at the launch's
+    target, and the relaunch has to finish that step -- proposal, likelihood, accept test -- before anything else."""
+    dim, n = 6, 64
+    e, chains = _make(gpu, oracle, dim, n, 0, which=(0, 1, 17, 63))
+    _step(e, chains, 50)
+    bad = np.eye(dim)
+    bad[0, 1] = bad[1, 0] = 1.0 + 1e-3
+    e.SetCovariance(bad)
+    for ch in chains.values():
+        ch.set_covariance(bad)
+    _both(e, chains, "SetCovarianceWindow", "set_covariance_window", 10 ** 6)
+    _both(e, chains, "SetCovarianceTrials", "set_covariance_trials", 1e6)
+    _both(e, chains, "SetNextUpdate", "set_next_update", 3)
+    for i in range(60):
+        _step(e, chains, 1)
+        if i % 10 == 9:
+            _same(e, chains, f"one step per launch, step {i + 1}")
+    assert np.all(e.lane("last_update_path") >= 1), "the ladder must have run in every chain"
+    assert np.all(e.lane("chain_steps") == 110)
+    _step(e, chains, 40)
+    _same(e, chains, "and on")
+
+
 def test_restore_continues_a_chain(gpu, oracle):
     """SaveStep(true) / Restore (TSimpleMCMC.H:282-352, 1501-1612) per chain: chain 3's saved state restored into every
     chain of a new engine = oracle.Chain.restore."""

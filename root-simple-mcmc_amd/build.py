@@ -53,7 +53,7 @@ def _units(user_flag=None):
              hmc, ("smcmc_hmc_mfma_inst.hip", [], "hmc_mfma"),
              vaat, ("smcmc_vaat_large.hip", [], "vaat_large"),
              ("smcmc_pooled_update.hip", [], "pooled_update"), ("smcmc_perchain_inst.hip", [], "perchain"),
-             ("smcmc_panel_mfma_inst.hip", [], "panel_mfma")]
+             ("smcmc_panel_mfma_inst.hip", [], "panel_mfma"), ("smcmc_fold_inst.hip", [], "fold")]
     for dp in dp_list():
         for like in LIKELIHOODS:
             units.append(("smcmc_inst.hip", [f"-DSMCMC_DP={dp}", f"-DSMCMC_LIKE={like}"], f"inst_dp{dp}_l{like}"))

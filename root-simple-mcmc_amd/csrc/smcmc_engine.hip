@@ -20,7 +20,7 @@
 #include "smcmc_panel_kernel.hip.h"
 #include "smcmc_panel_mfma_kernel.hip.h"
 #include "smcmc_pooled_update.hip.h"
-#include "smcmc_fold_kernel.hip.h"
+#include "smcmc_fold_ring.hip.h"
 #include "smcmc_perchain_kernel.hip.h"
 #include "smcmc_proposal.hpp"
 
@@ -115,6 +115,7 @@ struct smcmc_engine {
     double* d_ring = nullptr;      // [ring_steps][dim][npad]
     double* d_ring_logl = nullptr; // [ring_steps][npad] (the kernels save both)
     int ring_steps = -1;           // -1: not decided yet; 0: no ring (the state is too large), else steps per launch
+    smcmc::FoldRing fold;          // dim > 63: the fold kernel's plan for this ensemble (smcmc_fold_ring.hip.h)
     ncclComm_t comm = nullptr;     // smcmc_comm_init
     int comm_ranks = 0;
     double* d_proposed = nullptr;  // [dp][npad], allocated by SMCMC_P_KEEP_PROPOSED
@@ -650,19 +651,36 @@ int device_apply(smcmc_engine* h) {
 int ensure_ring(smcmc_engine* h) {
     if (h->ring_steps >= 0) return SMCMC_OK;
     const size_t state = sizeof(double) * (size_t)h->npad * h->dim;
-    size_t steps = ((size_t)2 << 30) / state;
-    if (steps > 8) steps = 8;
+    size_t steps = ((size_t)4 << 30) / state;
+    if (steps > (size_t)smcmc::kFoldMaxSrc) steps = smcmc::kFoldMaxSrc;   // one fold launch takes the whole ring
     if (steps < 2) { h->ring_steps = 0; return SMCMC_OK; }
     // no memory for the ring is no error: the one-step launches with a fold between them need none
     if (hipMalloc(&h->d_ring, state * steps) != hipSuccess ||
         hipMalloc(&h->d_ring_logl, sizeof(double) * (size_t)h->npad * steps) != hipSuccess) {
         (void)hipGetLastError();
         (void)hipFree(h->d_ring); (void)hipFree(h->d_ring_logl);
+    smcmc::fold_ring_release(h->fold);
         h->d_ring = nullptr; h->d_ring_logl = nullptr;
         h->ring_steps = 0;
         return SMCMC_OK;
     }
     h->ring_steps = (int)steps;
+    return SMCMC_OK;
+}
+
+// Folds `n` points ([dim][npad] each, in this order) into the moment groups: one launch, the accumulators in registers
+// from the first point to the last.
+int fold_points(smcmc_engine* h, const double* const* pts, int n) {
+    for (int done = 0; done < n; done += smcmc::kFoldMaxSrc) {
+        smcmc::FoldRingParams fp;
+        std::memset(&fp, 0, sizeof(fp));
+        fp.nsrc = std::min(n - done, (int)smcmc::kFoldMaxSrc);
+        for (int k = 0; k < fp.nsrc; ++k) fp.src[k] = pts[done + k];
+        fp.c0 = h->d_c0; fp.nchains = h->nchains; fp.npad = h->npad; fp.D = h->dim; fp.slice_chains = h->slice_chains;
+        fp.gacc = h->d_gacc; fp.mask = nullptr;
+        const hipError_t e = smcmc::launch_fold_ring(h->fold, fp, h->stream);
+        if (e != hipSuccess) return fail(h, SMCMC_ERR_HIP, std::string("fold kernel launch: ") + hipGetErrorString(e));
+    }
     return SMCMC_OK;
 }
 
@@ -1008,16 +1026,21 @@ int launch(smcmc_engine* h, int nsteps, int metropolis, int stride, double* save
             int rst = ensure_ring(h);
             if (rst) return rst;
         }
+        // x_folded: the point in d_x has already gone into the moments (as the last slot of the previous segment's ring)
+        bool x_folded = false;
         while (done < nsteps) {
             int seg = nsteps - done;
             if (ring_wanted && h->ring_steps >= 2 && seg >= 2) {
                 seg = std::min(seg, h->ring_steps);
-                hipError_t e = launch_fold(h->d_x, h->d_c0, h->nchains, h->npad, h->dim, h->slice_chains, h->fold_nslices, h->d_gacc,
-                                           h->stream);
-                if (e != hipSuccess) return fail(h, SMCMC_ERR_HIP, std::string("fold kernel launch: ") + hipGetErrorString(e));
+                if (!x_folded) {
+                    const double* px = h->d_x;
+                    const int fst = fold_points(h, &px, 1);
+                    if (fst) return fst;
+                }
                 q.nsteps = seg;
                 q.step0 = h->total_steps;
                 q.save_x = h->d_ring; q.save_logl = h->d_ring_logl; q.save_stride = 1;
+                hipError_t e;
                 if (!exact) {
                     q.Uperm = h->d_Uop;
                     e = launch_panel_mfma(q, h->likelihood, h->stream);
@@ -1027,12 +1050,17 @@ int launch(smcmc_engine* h, int nsteps, int metropolis, int stride, double* save
                 }
                 if (e != hipSuccess) return fail(h, SMCMC_ERR_HIP, std::string("panel kernel launch: ") + hipGetErrorString(e));
                 q.save_x = nullptr; q.save_logl = nullptr;
-                // the point after step s of the launch is the one UpdateState sees at the start of step s + 1
-                for (int s = 0; s + 1 < seg; ++s) {
-                    e = launch_fold(h->d_ring + (size_t)s * h->dim * h->npad, h->d_c0, h->nchains, h->npad, h->dim, h->slice_chains,
-                                    h->fold_nslices, h->d_gacc, h->stream);
-                    if (e != hipSuccess) return fail(h, SMCMC_ERR_HIP, std::string("fold kernel launch: ") + hipGetErrorString(e));
+                // The point after step s of the launch is the one UpdateState sees at the start of step s + 1.  The one
+                // after the LAST step (= d_x) goes in here too when this call steps on; otherwise the next call folds it.
+                const bool more = done + seg < nsteps;
+                const int npts = more ? seg : seg - 1;
+                const double* pts[smcmc::kFoldMaxSrc];
+                for (int s = 0; s < npts; ++s) pts[s] = h->d_ring + (size_t)s * h->dim * h->npad;
+                if (npts > 0) {
+                    const int fst = fold_points(h, pts, npts);
+                    if (fst) return fst;
                 }
+                x_folded = more;
                 h->total_steps += (uint32_t)seg;
                 done += seg;
                 continue;
@@ -1040,11 +1068,12 @@ int launch(smcmc_engine* h, int nsteps, int metropolis, int stride, double* save
             if (pooled) {
                 const int phase = (int)(h->total_steps % (uint32_t)h->moment_stride);
                 // a forced step or a scan does not call UpdateState: nothing to fold
-                if (phase == 0 && !q.has_forced && q.scan_dim < 0) {
-                    hipError_t e = launch_fold(h->d_x, h->d_c0, h->nchains, h->npad, h->dim, h->slice_chains, h->fold_nslices, h->d_gacc,
-                                               h->stream);
-                    if (e != hipSuccess) return fail(h, SMCMC_ERR_HIP, std::string("fold kernel launch: ") + hipGetErrorString(e));
+                if (phase == 0 && !q.has_forced && q.scan_dim < 0 && !x_folded) {
+                    const double* px = h->d_x;
+                    const int fst = fold_points(h, &px, 1);
+                    if (fst) return fst;
                 }
+                x_folded = false;
                 seg = std::min(seg, h->moment_stride - phase);
             }
             if (q.has_forced) seg = 1;   // the forced step is a launch of its own (FORCED instantiation of the fused kernel)
@@ -1140,6 +1169,7 @@ int smcmc_create(int dim, int nchains, int likelihood, uint64_t seed, uint32_t c
     h->prop = new SharedProposal(dim);
     *out = h;
     ON_DEVICE(h);
+    if (panel_w) HIP_TRY(h, smcmc::fold_ring_prepare(h->fold, dim, nchains, h->npad, h->fold_nslices, h->slice_chains));
     const size_t np = (size_t)h->npad;
     const size_t u_doubles = panel_w ? (size_t)panel_w * dim * kPanelCW : (size_t)dp * dp;
     HIP_TRY(h, hipMalloc(&h->d_x, sizeof(double) * np * dp));        // rows >= dim stay zero

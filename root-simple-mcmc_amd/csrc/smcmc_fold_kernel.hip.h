@@ -1,16 +1,13 @@
-// smcmc_fold_kernel.hip.h -- pooled second moments for the large-dimension path.
+// smcmc_fold_kernel.hip.h -- pooled second moments for the large-dimension path: the moment groups and their
+// ordered reduction.
 //
-// For D > 63 the (D+1)(D+2)/2 accumulators of a 64-chain group no longer fit a
-// wavefront's registers, so the fold of the current point into the moment sums
-// (the batch form of the running covariance, reference TSimpleMCMC.H:1795-1820)
-// runs as its own kernel between step launches: one wavefront per (4 x 4 block of
-// 16x16 output tiles, chain slice), four such wavefronts (a 2 x 2 arrangement of blocks)
-// sharing the operand tiles their workgroup stages, y = x - c0 from the [dim][chain]
-// state (staged through LDS in 256-byte runs), chains of the slice folded in ascending
-// order by chains of v_mfma_f64_16x16x4_f64.
-// The accumulators persist in HBM across folds; the slice sums are added in slice
-// order by fold_reduce_kernel.  oracle/ensemble_oracle.c mirrors this order with
-// moment groups of `slice_chains` chains.
+// For D > 63 the (D+1)(D+2)/2 accumulators of a 64-chain group no longer fit a wavefront's registers, so the fold
+// of the current point into the moment sums (the batch form of the running covariance, reference
+// TSimpleMCMC.H:1795-1820) runs as its own kernel between step launches (smcmc_fold_ring.hip.h): per chain slice
+// (moment group) and 16 x 16 tile of the lower triangle one accumulator tile that persists in HBM, y = x - c0 of the
+// slice's chains folded in ascending order by chains of v_mfma_f64_16x16x4_f64.  The slice sums are added in slice
+// order by fold_reduce_kernel.  oracle/ensemble_oracle.c mirrors this order with moment groups of `slice_chains`
+// chains.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -20,155 +17,23 @@
 
 namespace smcmc {
 
-constexpr int kFoldSlices = 128;  // most chain slices (moment groups) of the large-dimension path (32 until round 2: at
-                                  // D = 200 that left two thirds of the SIMDs without a wavefront)
-constexpr int kFoldBT = 4;        // a wavefront folds a block of kFoldBT x kFoldBT tiles (64 x 64 moments)
-constexpr int kFoldSB = 2;        // a workgroup folds kFoldSB x kFoldSB such blocks of the same chain slice
-constexpr int kFoldWaves = kFoldSB * kFoldSB;
-constexpr int kFoldOps = 2 * kFoldSB * kFoldBT;   // operand tiles a workgroup stages: its row group and its column group
+constexpr int kFoldSlices = 128;  // most chain slices (moment groups) of the large-dimension path
+constexpr int kFoldBT = 4;        // geometry of the fold kernel of rounds 1-3 (a wavefront folded 4 x 4 tiles, a
+constexpr int kFoldSB = 2;        // workgroup 2 x 2 such blocks): it still DEFINES the number of moment groups below
 
-// super-blocks (workgroups per slice): the lower triangle of the kFoldSB * kFoldBT-tile grid
+// super-blocks of that geometry: the lower triangle of the kFoldSB * kFoldBT-tile grid
 inline int fold_super_blocks(int D) {
     const int T = (D + 1 + 15) / 16, TB = (T + kFoldBT - 1) / kFoldBT, SB = (TB + kFoldSB - 1) / kFoldSB;
     return SB * (SB + 1) / 2;
 }
-// Slices actually used: as many as give every CU at most one workgroup (one wavefront per SIMD), so that a fold is
-// one round of workgroups with no tail.
+// The number of moment groups: part of the engine's definition (the groups' sums are added in order, so the count
+// shapes the last bits of the pooled moments; the oracle takes it from SMCMC_P_MOMENT_GROUP).  It is what gave the old
+// kernel one workgroup per CU and has been kept since, so that results do not move with the kernel.
 inline int fold_slices(int D) {
     int n = 256 / fold_super_blocks(D);
     if (n > kFoldSlices) n = kFoldSlices;
     if (n < 1) n = 1;
     return n;
-}
-
-// grid = (super-blocks, slices), block = 256.  Wavefront (a2, b2) of the workgroup owns block (2 BI + a2, 2 BJ + b2) of
-// 4 x 4 tiles: eight operand tiles feed its sixteen matrix instructions per four chains.  The workgroup stages the
-// sixteen operand tiles of its row group and column group once for all four wavefronts (round 1 staged eight tiles per
-// wavefront and read the state nine times over at D = 500: 1.2 GB per fold, which bound it; now 0.6 GB).  The state is
-// read in full cache lines (lane -> row lane >> 2, four consecutive chains), one stage of 16 chains ahead of its use,
-// and re-laid out through LDS into the operand layout (row lane & 15, chain 4 n + (lane >> 4)).
-// mask (optional, [npad]): a chain with mask 0 folds nothing this time (the HMC engine: a step whose proposal had a
-// non-finite potential skips UpdateCovariance, TSimpleHMC.H:336)
-static __global__ void __launch_bounds__(kFoldWaves* kWave) fold_moments_kernel(const double* __restrict__ x, const double* __restrict__ c0,
-                                                             int nchains, int npad, int D, int slice_chains,
-                                                             double* __restrict__ gacc, const int32_t* __restrict__ mask) {
-    constexpr int kC = 32;        // chains per stage: 256 contiguous bytes of every staged row (16 chains = 128-byte
-                                  // pieces of 64 000 concurrent row streams ran the memory system at a fifth of its rate;
-                                  // 64 chains per stage measured no better than 32)
-    constexpr int kS = kC + 2;    // doubles per staged row: the chains + 2 (operand reads spread over the banks)
-    constexpr int kL = kC / 8;    // 16-byte loads per lane and operand tile (a lane holds kC / 4 consecutive chains of one row)
-    __shared__ __attribute__((aligned(16))) double st[kFoldOps][16][kS];
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wv = threadIdx.x / kWave;
-    const int slice = blockIdx.y;
-    const int T = (D + 1 + 15) / 16, ntiles = T * (T + 1) / 2, TB = (T + kFoldBT - 1) / kFoldBT;
-    int BI = 0;
-    while ((BI + 1) * (BI + 2) / 2 <= (int)blockIdx.x) ++BI;
-    const int BJ = (int)blockIdx.x - BI * (BI + 1) / 2;
-    const bool sdiag = (BI == BJ);                      // the column group is the row group
-    const int a2 = wv / kFoldSB, b2 = wv % kFoldSB;
-    const int bi = kFoldSB * BI + a2, bj = kFoldSB * BJ + b2;
-    const bool mine = bi < TB && bj <= bi;              // this wavefront has a block (it stages its share either way)
-    const bool diagonal = (bi == bj);
-    const int nops = sdiag ? kFoldSB * kFoldBT : kFoldOps;
-    const int colbase = sdiag ? 0 : kFoldSB * kFoldBT;  // first staged tile of the column group
-    const size_t NP = (size_t)npad;
-    // staging role of this lane: row (lane >> 2) of the wavefront's share of the operand tiles, kC / 4 consecutive chains
-    const int srow = lane >> 2, sq = lane & 3;
-    constexpr int kShare = kFoldOps / kFoldWaves;       // operand tiles a wavefront fetches per stage
-    int rr[kShare];
-    double cc[kShare];
-#pragma unroll
-    for (int q = 0; q < kShare; ++q) {
-        const int op = wv + kFoldWaves * q;
-        const int tile = (op < kFoldSB * kFoldBT) ? kFoldSB * kFoldBT * BI + op : kFoldSB * kFoldBT * BJ + (op - kFoldSB * kFoldBT);
-        rr[q] = 16 * tile + srow;
-        cc[q] = (rr[q] < D) ? c0[rr[q]] : 0.0;
-    }
-    // tile (ti, tj) of the block: valid when it exists and lies in the lower triangle
-    auto valid = [&](int a, int b) { return mine && kFoldBT * bi + a < T && kFoldBT * bj + b <= kFoldBT * bi + a; };
-    auto offset = [&](int a, int b) {
-        const int ti = kFoldBT * bi + a, tj = kFoldBT * bj + b;
-        return (((size_t)slice * ntiles + (size_t)(ti * (ti + 1) / 2 + tj)) * 4) * kWave + lane;
-    };
-    f64x4 acc[kFoldBT][kFoldBT];
-#pragma unroll
-    for (int a = 0; a < kFoldBT; ++a)
-#pragma unroll
-        for (int b = 0; b < kFoldBT; ++b)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[a][b][r] = valid(a, b) ? gacc[offset(a, b) + (size_t)r * kWave] : 0.0;
-    const int c_begin = slice * slice_chains;
-    const int c_end = (c_begin + slice_chains < npad) ? c_begin + slice_chains : npad;
-
-    typedef f64x2 stage_t[kShare][kL];
-    stage_t stA, stB;   // two stages of kC chains in flight ahead of the matrix instructions
-    auto fetch = [&](int c, stage_t& stage) {   // y = x - c0 (the constant 1 in row D, 0 above, 0 for chains past the ensemble)
-        const int chain = c + 2 * kL * sq;
-        bool on[2 * kL];
-#pragma unroll
-        for (int k = 0; k < 2 * kL; ++k) on[k] = (chain + k < nchains) && (mask == nullptr || mask[chain + k] != 0);
-#pragma unroll
-        for (int q = 0; q < kShare; ++q) {
-            if (wv + kFoldWaves * q >= nops) continue;
-#pragma unroll
-            for (int k = 0; k < kL; ++k) {
-                f64x2 v = {0.0, 0.0};
-                if (rr[q] < D) {
-                    v = ((const f64x2*)(x + (size_t)rr[q] * NP + chain))[k];
-                    v[0] -= cc[q]; v[1] -= cc[q];
-                } else if (rr[q] == D) {
-                    v[0] = v[1] = 1.0;
-                }
-                if (!on[2 * k]) v[0] = 0.0;
-                if (!on[2 * k + 1]) v[1] = 0.0;
-                stage[q][k] = v;
-            }
-        }
-    };
-    // one stage: registers -> LDS (every wavefront its share), refill the registers two stages ahead, fold the 16 chains.
-    // All wavefronts of the workgroup walk the same slice, so the barriers are uniform.
-    auto consume = [&](int c, stage_t& stage) {
-        __syncthreads();   // the previous stage has been consumed by every wavefront
-#pragma unroll
-        for (int q = 0; q < kShare; ++q) {
-            const int op = wv + kFoldWaves * q;
-            if (op >= nops) continue;
-#pragma unroll
-            for (int k = 0; k < kL; ++k) *(f64x2*)&st[op][srow][2 * kL * sq + 2 * k] = stage[q][k];
-        }
-        __syncthreads();
-        if (c + 2 * kC < c_end) fetch(c + 2 * kC, stage);   // in flight under the matrix instructions
-        if (!mine) return;
-#pragma unroll
-        for (int n = 0; n < kC / 4; ++n) {
-            double av[kFoldBT], bv[kFoldBT];
-#pragma unroll
-            for (int a = 0; a < kFoldBT; ++a) {
-                av[a] = st[kFoldBT * a2 + a][lane & 15][4 * n + (lane >> 4)];
-                bv[a] = diagonal ? av[a] : st[colbase + kFoldBT * b2 + a][lane & 15][4 * n + (lane >> 4)];
-            }
-#pragma unroll
-            for (int a = 0; a < kFoldBT; ++a)
-#pragma unroll
-                for (int b = 0; b < kFoldBT; ++b)
-                    if (valid(a, b)) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], acc[a][b], 0, 0, 0);
-        }
-    };
-    if (c_begin < c_end) fetch(c_begin, stA);
-    if (c_begin + kC < c_end) fetch(c_begin + kC, stB);
-    for (int c = c_begin; c < c_end; c += 2 * kC) {
-        consume(c, stA);
-        if (c + kC < c_end) consume(c + kC, stB);
-    }
-#pragma unroll
-    for (int a = 0; a < kFoldBT; ++a)
-#pragma unroll
-        for (int b = 0; b < kFoldBT; ++b)
-            if (valid(a, b)) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) gacc[offset(a, b) + (size_t)r * kWave] = acc[a][b][r];
-            }
 }
 
 // packed element k = (i, j), j <= i <= D  ->  sum over slices of its tile entry, in the order of every moment reduction
@@ -196,8 +61,6 @@ static __global__ void fold_reduce_kernel(const double* __restrict__ gacc, int n
     moments[k] = total;
 }
 
-hipError_t launch_fold(const double* x, const double* c0, int nchains, int npad, int D, int slice_chains, int nslices,
-                       double* gacc, hipStream_t stream, const int32_t* mask = nullptr);
 hipError_t launch_fold_reduce(const double* gacc, int D, int nslices, double* moments, hipStream_t stream);
 
 }  // namespace smcmc

@@ -30,6 +30,7 @@
 #include <utility>
 #include <vector>
 
+#include "smcmc_fold_kernel.hip.h"
 #include "smcmc_kernels.hip.h"
 
 namespace smcmc {
@@ -200,6 +201,9 @@ __device__ __forceinline__ void fr_put_round(FrWave<NQ, MASKED>& w, int q, int p
 // Staging round Q of the next stage (Q == NQ: the constant 1 row and, MASKED, the mask words of the stage after it).
 template <int Q, int NQ, bool MASKED, int PAR>
 __device__ __forceinline__ void fr_round(FrWave<NQ, MASKED>& w, const FoldRingParams& p, bool on0, bool on1, int chain_next) {
+#ifdef FR_EXP_NO_STAGING
+    return;
+#endif
     if constexpr (Q < NQ) {
         fr_put_round<MASKED>(w, Q, 1 - PAR, on0, on1);
         fr_fetch_round(w, Q);
@@ -233,7 +237,13 @@ __device__ __forceinline__ void fr_step(FrWave<NQ, MASKED>& w, const FoldRingPar
         ra[I % LA] = w.aA[(I + LA) % NT][so + 4 * ((I + LA) / NT)];
         rb[I % LA] = w.aB[(I + LA) % NT][so + 4 * ((I + LA) / NT)];
     }
+#ifdef FR_EXP_NO_MFMA
+    w.acc[I % NT][0] += a * b;
+#elif defined(FR_EXP_ONE_READ)
+    w.acc[I % NT] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, w.acc[I % NT], 0, 0, 0);
+#else
     w.acc[I % NT] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, w.acc[I % NT], 0, 0, 0);
+#endif
     __builtin_amdgcn_sched_barrier(0);
     fr_rounds<(I * R) / N, ((I + 1) * R) / N, NQ, MASKED, PAR>(w, p, on0, on1, chain_next);
 }
@@ -406,6 +416,14 @@ static __global__ void __launch_bounds__(kFrWaves* kWave, 1) __attribute__((amdg
         }
 }
 
-hipError_t launch_fold_ring(const FoldRingParams& p, int nwg, hipStream_t stream);
+// Host side (smcmc_fold_inst.hip): the plan of an engine on its device, and the launch.
+struct FoldRing {
+    FoldPlanEntry* d_plan = nullptr;
+    int nwg = 0;                      // workgroups of a launch = plan entries (a multiple of 8)
+};
+hipError_t fold_ring_prepare(FoldRing& fr, int D, int nchains, int npad, int nslices, int slice_chains);
+void fold_ring_release(FoldRing& fr);
+// p.plan is taken from fr; p.nsrc points in p.src are folded in order (1 <= nsrc <= kFoldMaxSrc)
+hipError_t launch_fold_ring(const FoldRing& fr, FoldRingParams p, hipStream_t stream);
 
 }  // namespace smcmc

@@ -20,7 +20,7 @@
 #include "smcmc.h"
 #include "smcmc_hmc_kernel.hip.h"
 #include "smcmc_hmc_mfma_kernel.hip.h"
-#include "smcmc_fold_kernel.hip.h"
+#include "smcmc_fold_ring.hip.h"
 #include "smcmc_hmc_shared.hpp"
 
 using namespace smcmc;
@@ -47,6 +47,7 @@ struct smcmc_hmc {
     int sync_every = 1, steps_in_window = 0;
     int steps_reduced = 0;   // steps whose moments are in d_moments, waiting for hmc_apply (between reduce and apply)
     int fold_nslices = 0, slice_chains = 0;
+    smcmc::FoldRing fold;   // the fold kernel's plan for this ensemble
     double *d_p0 = nullptr, *d_qprev = nullptr, *d_gacc = nullptr, *d_moments = nullptr, *d_zero = nullptr;
     double* h_moments = nullptr;   // pinned: the packed moments come back every sync
     // PotentialGradient types 2 / 3 / 5 (TSimpleHMC.H:467-532): the GENERIC instantiation of hmc_step_kernel
@@ -223,6 +224,7 @@ int hmc_tracking_buffers(smcmc_hmc* h) {
     HMC_TRY(h, hipMalloc(&h->d_p0, vec));
     HMC_TRY(h, hipMalloc(&h->d_qprev, vec));
     HMC_TRY(h, hipMalloc(&h->d_gacc, sizeof(double) * hmc_gacc_doubles(h)));
+    HMC_TRY(h, smcmc::fold_ring_prepare(h->fold, h->dim, h->nchains, h->npad, h->fold_nslices, h->slice_chains));
     HMC_TRY(h, hipMalloc(&h->d_moments, sizeof(double) * hmc_npacked(h)));
     HMC_TRY(h, hipMalloc(&h->d_zero, sizeof(double) * h->dim));
     HMC_TRY(h, hipHostMalloc((void**)&h->h_moments, sizeof(double) * hmc_npacked(h), hipHostMallocDefault));
@@ -456,6 +458,7 @@ int smcmc_hmc_destroy(smcmc_hmc* h) {
     (void)hipFree(h->d_q); (void)hipFree(h->d_pm); (void)hipFree(h->d_qn); (void)hipFree(h->d_pn);
     (void)hipFree(h->d_E); (void)hipFree(h->d_like); (void)hipFree(h->d_lane_f64); (void)hipFree(h->d_lane_i32);
     (void)hipFree(h->d_p0); (void)hipFree(h->d_qprev); (void)hipFree(h->d_gacc); (void)hipFree(h->d_moments);
+    smcmc::fold_ring_release(h->fold);
     (void)hipFree(h->d_zero); (void)hipFree(h->d_Eperm); (void)hipFree(h->d_covE); (void)hipFree(h->d_cov_avg);
     (void)hipFree(h->d_avg); (void)hipFree(h->d_exxt); (void)hipFree(h->d_hcov); (void)hipFree(h->d_hscal);
     (void)hipHostFree(h->h_hscal);
@@ -709,8 +712,14 @@ int smcmc_hmc_step(smcmc_hmc* h, int nsteps) {
         if (e != hipSuccess) return hfail(h, SMCMC_ERR_HIP, std::string("hmc step launch: ") + hipGetErrorString(e));
         h->step_count += 1u;
         // UpdateCovariance (:338): the point each chain stood on, if its proposal's potential was finite (:336)
-        e = launch_fold(h->d_qprev, h->d_zero, h->nchains, h->npad, h->dim, h->slice_chains, h->fold_nslices, h->d_gacc,
-                        h->stream, h->d_lane_i32 + (size_t)kHmcLaneContributes * h->npad);
+        {
+            smcmc::FoldRingParams fp;
+            std::memset(&fp, 0, sizeof(fp));
+            fp.src[0] = h->d_qprev; fp.nsrc = 1; fp.c0 = h->d_zero;
+            fp.nchains = h->nchains; fp.npad = h->npad; fp.D = h->dim; fp.slice_chains = h->slice_chains;
+            fp.gacc = h->d_gacc; fp.mask = h->d_lane_i32 + (size_t)kHmcLaneContributes * h->npad;
+            e = smcmc::launch_fold_ring(h->fold, fp, h->stream);
+        }
         if (e != hipSuccess) return hfail(h, SMCMC_ERR_HIP, std::string("fold launch: ") + hipGetErrorString(e));
         if (++h->steps_in_window >= h->sync_every) {
             st = hmc_sync(h);

@@ -45,22 +45,6 @@ hipError_t launch_panel<SMCMC_PANEL_W, kPanelCW>(const PanelParams& p, int like,
 }
 
 #if SMCMC_PANEL_W == 4
-hipError_t launch_fold(const double* x, const double* c0, int nchains, int npad, int D, int slice_chains, int nslices,
-                       double* gacc, hipStream_t s, const int32_t* mask) {
-    if (nslices < 1 || nslices > kFoldSlices) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(fold_moments_kernel, dim3(fold_super_blocks(D), nslices), dim3(kFoldWaves * kWave), 0, s, x, c0,
-                       nchains, npad, D, slice_chains, gacc, mask);
-    return hipGetLastError();
-}
-
-hipError_t launch_fold_reduce(const double* gacc, int D, int nslices, double* moments, hipStream_t s) {
-    const int T = (D + 1 + 15) / 16, ntiles = T * (T + 1) / 2;
-    const int npk = (D + 1) * (D + 2) / 2;
-    hipLaunchKernelGGL(fold_reduce_kernel, dim3((npk + 255) / 256), dim3(256), 0, s, gacc, ntiles, nslices, D,
-                       moments);
-    return hipGetLastError();
-}
-
 hipError_t launch_start_loglike(const double* x, int nchains, size_t npad, int D, const double* like_params,
                                 double* logl_out, int like, bool exact, hipStream_t s) {
     const dim3 grid((nchains + 255) / 256), block(256);

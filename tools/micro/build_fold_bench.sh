@@ -6,7 +6,7 @@ ROOT=$(cd "$(dirname "$0")/../.." && pwd)
 OUT=$ROOT/root-simple-mcmc_amd/build/micro
 mkdir -p $OUT
 cd $OUT
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I$ROOT/include -I$ROOT/root-simple-mcmc_amd/csrc \
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I$ROOT/include -I$ROOT/root-simple-mcmc_amd/csrc -I$ROOT/tools/micro \
     $ROOT/tools/micro/fold_bench.hip -o fold_bench -save-temps=obj
 S=fold_bench-hip-amdgcn-amd-amdhsa-gfx950.s
 for k in ILi16ELb0E ILi7ELb0E ILi16ELb1E; do

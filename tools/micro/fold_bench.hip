@@ -10,8 +10,8 @@
 #include <random>
 #include <vector>
 
-#include "smcmc_fold_kernel.hip.h"
 #include "smcmc_fold_ring.hip.h"
+#include "fold_moments_old.hip.h"
 
 using namespace smcmc;
 
@@ -24,29 +24,7 @@ using namespace smcmc;
         }                                                                                        \
     } while (0)
 
-namespace smcmc {
-template <int NQ, bool MASKED>
-static hipError_t go_fold_ring(const FoldRingParams& p, int nwg, hipStream_t stream) {
-    static bool attr = false;
-    if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fold_ring_kernel<NQ, MASKED>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)fold_ring_lds_bytes(NQ));
-        if (e != hipSuccess) return e;
-        attr = true;
-    }
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(fold_ring_kernel<NQ, MASKED>), dim3(nwg), dim3(kFrWaves * kWave), fold_ring_lds_bytes(NQ),
-                       stream, p);
-    return hipGetLastError();
-}
-hipError_t launch_fold_ring(const FoldRingParams& p, int nwg, hipStream_t stream) {
-    switch (fold_ring_rounds(p.D)) {
-#define SMCMC_FR_GO(n) case n: return p.mask ? go_fold_ring<n, true>(p, nwg, stream) : go_fold_ring<n, false>(p, nwg, stream);
-        SMCMC_FR_GO(4) SMCMC_FR_GO(7) SMCMC_FR_GO(10) SMCMC_FR_GO(13) SMCMC_FR_GO(16)
-#undef SMCMC_FR_GO
-        default: return hipErrorInvalidValue;
-    }
-}
-}  // namespace smcmc
+#include "../../root-simple-mcmc_amd/csrc/smcmc_fold_inst.hip"
 
 static void run_case(const char* name, int D, int nchains, int nsrc, bool masked, int reps) {
     const int npad = (nchains + 63) / 64 * 64;
@@ -77,9 +55,8 @@ static void run_case(const char* name, int D, int nchains, int nsrc, bool masked
     hipDeviceProp_t prop;
     CK(hipGetDeviceProperties(&prop, 0));
     auto plan = fold_ring_plan(D, nchains, npad, nslices, slice_chains, prop.multiProcessorCount);
-    FoldPlanEntry* dplan;
-    CK(hipMalloc(&dplan, sizeof(FoldPlanEntry) * plan.size()));
-    CK(hipMemcpy(dplan, plan.data(), sizeof(FoldPlanEntry) * plan.size(), hipMemcpyHostToDevice));
+    FoldRing fr;
+    CK(fold_ring_prepare(fr, D, nchains, npad, nslices, slice_chains));
     int maxt = 0, used = 0;
     for (auto& e : plan) {
         if (e.ntiles) ++used;
@@ -99,8 +76,8 @@ static void run_case(const char* name, int D, int nchains, int nsrc, bool masked
     std::memset(&p, 0, sizeof(p));
     for (int k = 0; k < nsrc; ++k) p.src[k] = dx + state * k;
     p.nsrc = nsrc; p.c0 = dc0; p.nchains = nchains; p.npad = npad; p.D = D; p.slice_chains = slice_chains;
-    p.gacc = gb; p.mask = masked ? dmask : nullptr; p.plan = dplan;
-    auto new_folds = [&]() { CK(launch_fold_ring(p, (int)plan.size(), s)); };
+    p.gacc = gb; p.mask = masked ? dmask : nullptr;
+    auto new_folds = [&]() { CK(launch_fold_ring(fr, p, s)); };
     // bitwise check: two rounds each on zeroed accumulators
     CK(hipMemsetAsync(ga, 0, sizeof(double) * gacc_n, s));
     CK(hipMemsetAsync(gb, 0, sizeof(double) * gacc_n, s));
@@ -135,7 +112,7 @@ static void run_case(const char* name, int D, int nchains, int nsrc, bool masked
                 name, D, nchains, nsrc, (int)masked, nslices, slice_chains, used, maxt, bad, gacc_n, nonzero,
                 1e3 * ms_old / reps / nsrc, 1e3 * ms_new / reps / nsrc, floor_us);
     std::fflush(stdout);
-    CK(hipFree(dx)); CK(hipFree(dc0)); CK(hipFree(ga)); CK(hipFree(gb)); CK(hipFree(dmask)); CK(hipFree(dplan));
+    CK(hipFree(dx)); CK(hipFree(dc0)); CK(hipFree(ga)); CK(hipFree(gb)); CK(hipFree(dmask)); fold_ring_release(fr);
     CK(hipStreamDestroy(s));
 }
 

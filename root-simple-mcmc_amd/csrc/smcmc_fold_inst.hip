@@ -29,34 +29,44 @@ hipError_t go_fold_ring(const FoldRingParams& p, int nwg, hipStream_t stream) {
 
 hipError_t fold_ring_prepare(FoldRing& fr, int D, int nchains, int npad, int nslices, int slice_chains) {
     fold_ring_release(fr);
-    if (fold_ring_rounds(D) < 0) return hipErrorInvalidValue;
+    if ((D + 1 + 15) / 16 > kFrMaxFoot - 2) return hipErrorInvalidValue;
     int dev = 0, cus = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     if (e != hipSuccess) return e;
-    const std::vector<FoldPlanEntry> plan = fold_ring_plan(D, nchains, npad, nslices, slice_chains, cus > 0 ? cus : 256);
-    e = hipMalloc(&fr.d_plan, sizeof(FoldPlanEntry) * plan.size());
+    const FoldPlan plan = fold_ring_plan(D, nchains, npad, nslices, slice_chains, cus > 0 ? cus : 256);
+    if (plan.rounds < 0 || plan.max_tiles > kFrMaxT) return hipErrorInvalidValue;
+    e = hipMalloc(&fr.d_plan, sizeof(FoldPlanEntry) * plan.wg.size());
     if (e != hipSuccess) return e;
-    e = hipMemcpy(fr.d_plan, plan.data(), sizeof(FoldPlanEntry) * plan.size(), hipMemcpyHostToDevice);
+    e = hipMemcpy(fr.d_plan, plan.wg.data(), sizeof(FoldPlanEntry) * plan.wg.size(), hipMemcpyHostToDevice);
     if (e != hipSuccess) return e;
-    fr.nwg = (int)plan.size();
+    e = hipMalloc(&fr.d_order, sizeof(uint16_t) * plan.order.size());
+    if (e != hipSuccess) return e;
+    e = hipMemcpy(fr.d_order, plan.order.data(), sizeof(uint16_t) * plan.order.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) return e;
+    fr.nwg = (int)plan.wg.size();
+    fr.rounds = plan.rounds;
     return hipSuccess;
 }
 
 void fold_ring_release(FoldRing& fr) {
     if (fr.d_plan) (void)hipFree(fr.d_plan);
+    if (fr.d_order) (void)hipFree(fr.d_order);
     fr.d_plan = nullptr;
+    fr.d_order = nullptr;
     fr.nwg = 0;
+    fr.rounds = 0;
 }
 
 hipError_t launch_fold_ring(const FoldRing& fr, FoldRingParams p, hipStream_t stream) {
     if (!fr.d_plan || fr.nwg < 8 || p.nsrc < 1 || p.nsrc > kFoldMaxSrc) return hipErrorInvalidValue;
     p.plan = fr.d_plan;
-    switch (fold_ring_rounds(p.D)) {
+    p.order = fr.d_order;
+    switch (fr.rounds) {
 #define SMCMC_FR_GO(n) \
     case n: return p.mask ? go_fold_ring<n, true>(p, fr.nwg, stream) : go_fold_ring<n, false>(p, fr.nwg, stream);
-        SMCMC_FR_GO(4) SMCMC_FR_GO(7) SMCMC_FR_GO(10) SMCMC_FR_GO(13) SMCMC_FR_GO(16)
+        SMCMC_FR_GO(2) SMCMC_FR_GO(4) SMCMC_FR_GO(5) SMCMC_FR_GO(7) SMCMC_FR_GO(9)
 #undef SMCMC_FR_GO
         default: return hipErrorInvalidValue;
     }

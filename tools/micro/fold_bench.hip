@@ -26,7 +26,7 @@ using namespace smcmc;
 
 #include "../../root-simple-mcmc_amd/csrc/smcmc_fold_inst.hip"
 
-static void run_case(const char* name, int D, int nchains, int nsrc, bool masked, int reps) {
+static void run_case(const char* name, int D, int nchains, int nsrc, bool masked, int reps, bool same = false) {
     const int npad = (nchains + 63) / 64 * 64;
     const int ngroups = npad / 64;
     const int nslices = fold_slices(D);
@@ -57,11 +57,11 @@ static void run_case(const char* name, int D, int nchains, int nsrc, bool masked
     auto plan = fold_ring_plan(D, nchains, npad, nslices, slice_chains, prop.multiProcessorCount);
     FoldRing fr;
     CK(fold_ring_prepare(fr, D, nchains, npad, nslices, slice_chains));
-    int maxt = 0, used = 0;
-    for (auto& e : plan) {
-        if (e.ntiles) ++used;
-        maxt = std::max(maxt, (e.ntiles + kFrWaves - 1) / kFrWaves);
-    }
+    int maxt = plan.max_tiles, used = 0;
+    double foot = 0;
+    for (auto& e : plan.wg)
+        if (e.ntiles) { ++used; foot += e.nfoot; }
+    foot /= used;
     hipStream_t s;
     CK(hipStreamCreate(&s));
     hipEvent_t e0, e1;
@@ -70,11 +70,11 @@ static void run_case(const char* name, int D, int nchains, int nsrc, bool masked
     auto old_folds = [&]() {
         for (int k = 0; k < nsrc; ++k)
             hipLaunchKernelGGL(fold_moments_kernel, dim3(fold_super_blocks(D), nslices), dim3(kFoldWaves * kWave), 0, s,
-                               dx + state * k, dc0, nchains, npad, D, slice_chains, ga, masked ? dmask : nullptr);
+                               dx + (same ? 0 : state * k), dc0, nchains, npad, D, slice_chains, ga, masked ? dmask : nullptr);
     };
     FoldRingParams p;
     std::memset(&p, 0, sizeof(p));
-    for (int k = 0; k < nsrc; ++k) p.src[k] = dx + state * k;
+    for (int k = 0; k < nsrc; ++k) p.src[k] = dx + (same ? 0 : state * k);
     p.nsrc = nsrc; p.c0 = dc0; p.nchains = nchains; p.npad = npad; p.D = D; p.slice_chains = slice_chains;
     p.gacc = gb; p.mask = masked ? dmask : nullptr;
     auto new_folds = [&]() { CK(launch_fold_ring(fr, p, s)); };
@@ -107,9 +107,9 @@ static void run_case(const char* name, int D, int nchains, int nsrc, bool masked
     }
     const double kq = (double)npad / 4.0;
     const double floor_us = (double)ntiles * kq * 64.0 / 1024.0 / 2.4e3;
-    std::printf("%-28s D=%d chains=%d nsrc=%d mask=%d slices=%d x %d  plan: %d wg, <=%d tiles/wave | mismatches %zu of %zu (%zu nonzero)"
+    std::printf("%-28s D=%d chains=%d nsrc=%d mask=%d slices=%d x %d  plan: %d wg, <=%d tiles/wave, bands of %d, footprint %.1f (<= %d) of %d tiles, %d rounds | mismatches %zu of %zu (%zu nonzero)"
                 " | per fold: old %.1f us, new %.1f us (matrix-pipe floor %.1f us)\n",
-                name, D, nchains, nsrc, (int)masked, nslices, slice_chains, used, maxt, bad, gacc_n, nonzero,
+                name, D, nchains, nsrc, (int)masked, nslices, slice_chains, used, maxt, plan.band, foot, plan.max_foot, T, plan.rounds, bad, gacc_n, nonzero,
                 1e3 * ms_old / reps / nsrc, 1e3 * ms_new / reps / nsrc, floor_us);
     std::fflush(stdout);
     CK(hipFree(dx)); CK(hipFree(dc0)); CK(hipFree(ga)); CK(hipFree(gb)); CK(hipFree(dmask)); fold_ring_release(fr);
@@ -118,13 +118,17 @@ static void run_case(const char* name, int D, int nchains, int nsrc, bool masked
 
 int main(int argc, char** argv) {
     const int reps = argc > 1 ? std::atoi(argv[1]) : 20;
-    run_case("small ragged", 70, 200, 3, false, reps);
-    run_case("small masked", 100, 1000, 1, true, reps);
-    run_case("config 3, one point", 200, 16384, 1, false, reps);
-    run_case("config 3, ring of 8", 200, 16384, 8, false, reps);
-    run_case("config 4 share, one point", 500, 32768, 1, false, reps);
-    run_case("config 4 share, ring of 8", 500, 32768, 8, false, reps);
-    run_case("D=512 max", 512, 8192, 2, false, reps);
-    run_case("hmc config 5 masked", 500, 8192, 1, true, reps);
+    const char* only = argc > 2 ? argv[2] : nullptr;   // run the cases whose name contains this
+    struct Case { const char* name; int D, nchains, nsrc; bool masked; bool same = false; };
+    const Case cases[] = {{"small ragged", 70, 200, 3, false}, {"small masked", 100, 1000, 1, true},
+                          {"config 3, one point", 200, 16384, 1, false}, {"config 3, ring of 8", 200, 16384, 8, false},
+                          {"config 4 share, one point", 500, 32768, 1, false}, {"config 4 share, ring of 8", 500, 32768, 8, false},
+                          {"config 4 share, ring of 16", 500, 32768, 16, false},
+                          {"config 4 share, one point 8 times", 500, 32768, 8, false, true},
+                          {"config 4 share + 64 chains (row pitch not a power of two), ring of 8", 500, 32768 + 64, 8, false},
+                          {"config 3 + 64 chains, ring of 8", 200, 16384 + 64, 8, false},
+                          {"D=512 max", 512, 8192, 2, false}, {"hmc config 5 masked", 500, 8192, 1, true}};
+    for (const Case& c : cases)
+        if (!only || std::strstr(c.name, only)) run_case(c.name, c.D, c.nchains, c.nsrc, c.masked, reps, c.same);
     return 0;
 }

@@ -125,7 +125,7 @@ def fractions(rate, dim, like):
 
 
 def extra_metropolis(pkg, torch, stream, name, dim, chains, like, like_id, prm, x0, exact, windows, window=WINDOW,
-                     stride=1, dense_quadform=None):
+                     stride=1, dense_quadform=None, adapt_windows=4):
     """One of the other BASELINE configs: pooled covariance, `window` steps then a sync, timed with HIP events on the
     engine's stream (device time of the step launches, moment folds included) and with the wall clock (sync included)."""
     eng = pkg.Engine(dim, chains, likelihood=like_id, likelihood_params=prm, seed=20240607, mode=pkg.MODE_POOLED,
@@ -138,8 +138,10 @@ def extra_metropolis(pkg, torch, stream, name, dim, chains, like, like_id, prm, 
     quadform_walk = None
     if like_id == pkg.LIKE_QUADFORM:
         quadform_walk = "dense D^2-term sum" if eng.get_param("DENSE_QUADFORM") else "non-zero entries of Error only (bit for bit the dense sum)"
-    eng.Step(window); eng.sync()                      # warm-up window
+    for _ in range(adapt_windows):                    # adaptation windows before the timed ones (the proposal has settled)
+        eng.Step(window); eng.sync()
     torch.cuda.synchronize()
+    acc0, steps0 = float(eng.lane("naccept").sum()), eng.get_param("TOTAL_STEPS")
     gc.collect(); gc.disable()                        # a full collection of a torch-sized heap stalls the host for ~70 ms
     evs = []
     t0 = time.perf_counter()
@@ -158,8 +160,8 @@ def extra_metropolis(pkg, torch, stream, name, dim, chains, like, like_id, prm, 
     out = {"workload": name, "chain_steps_per_s": rate, "ms_per_window": dt / windows * 1e3, "step_launches_ms": kms,
            "ms_per_ensemble_step": kms / window, "windows": windows, "window": window,
            "arithmetic": "reference-order" if exact else "fused (matrix pipe)" if dim > 63 else "fused",
-           "moment_stride": stride,
-           "accept_rate": float(eng.lane("naccept").sum() / (eng.get_param("TOTAL_STEPS") * chains))}
+           "moment_stride": stride, "adaptation_windows_before": adapt_windows,
+           "accept_rate": float((eng.lane("naccept").sum() - acc0) / ((eng.get_param("TOTAL_STEPS") - steps0) * chains))}
     if quadform_walk:
         out["quadratic_form"] = quadform_walk
     out.update(fractions(rate, dim, like))
@@ -199,27 +201,21 @@ def extra_perchain(pkg, torch, stream, dim, chains, steps, launches, header_form
     return out
 
 
-def hmc_ess_per_trajectory(h, nsteps=48):
+def hmc_ess_per_trajectory(h, torch, nsteps=256):
     """Effective samples per trajectory of the running ensemble (outside any timed region): nsteps more trajectories,
-    the positions read back after each, the lag autocorrelation of every 16th coordinate pooled over the chains
-    (definition of MakeAutocorrelation.C:127-148), Geyer's initial positive sequence, the worst coordinate."""
-    trace = []
-    for _ in range(nsteps):
+    the positions of every chain copied into a device trace after each (smcmc_hmc_copy_positions: 8.4 GB at config 5,
+    nothing crosses PCIe), the lagged products pooled over the chains on the device (smcmc_autocorrelation_sums: the
+    definition of MakeAutocorrelation.C:127-148), Geyer's initial positive sequence, the worst coordinate."""
+    npad = h.nchains_padded
+    trace = torch.empty((nsteps, h.dim, npad), dtype=torch.float64, device="cuda")
+    for k in range(nsteps):
         h.Step(1)
-        q, _, _ = h.state()
-        trace.append(q[::16].copy())
-    x = np.array(trace)                                    # [step][coordinate][chain]
-    x = x - x.mean(axis=(0, 2), keepdims=True)
-    var = (x * x).mean(axis=(0, 2))
-    tau = np.ones(x.shape[1])
-    for d in range(x.shape[1]):
-        k = 1
-        while k + 1 < nsteps // 2:
-            pair = ((x[k:, d] * x[:-k, d]).mean() + (x[k + 1:, d] * x[:-k - 1, d]).mean()) / var[d]
-            if pair < 0:
-                break
-            tau[d] += 2.0 * pair
-            k += 2
+        h.copy_positions(trace[k].data_ptr())
+    torch.cuda.synchronize()
+    q, _, _ = h.state()
+    tau = h.AutocorrelationSums(trace.data_ptr(), nsteps, centre=q.mean(axis=1),
+                                stream=torch.cuda.current_stream().cuda_stream).tau()
+    del trace
     return 1.0 / float(tau.max())
 
 
@@ -270,7 +266,8 @@ def extra_hmc(pkg, torch, stream, dim, chains, leapfrog, exact, steps, tuned, bu
            "covariance_updates": h.tuning["updates"]}
     if ess:
         try:
-            per = hmc_ess_per_trajectory(h)
+            per = hmc_ess_per_trajectory(h, torch)
+            out["ess_trajectories"] = 256
             out["ess_per_trajectory"] = per
             out["ess_per_s"] = per * rate
         except Exception as exc:
@@ -294,10 +291,18 @@ def main():
     ap.add_argument("--dim", type=int, default=DIM, help="diagnostic: other dimension (not the headline)")
     ap.add_argument("--header-tdummy", action="store_true",
                     help="diagnostic: the headline loop on the other C2 likelihood (header-form TDummyLogLikelihood)")
+    ap.add_argument("--config", choices=("c2", "c4"), default="c2",
+                    help="c2 (default, the headline): BASELINE config 2, D=50, 65 536 chains per GPU.  c4: BASELINE config 4, "
+                         "D=500, 32 768 chains per GPU (262 144 over 8), all-reduce of the pooled covariance every 256 steps; "
+                         "README-form likelihood, or the header form with --header-tdummy")
     ap.add_argument("--native-comm", action="store_true",
                     help="N > 1: the moment all-reduce through the library's own RCCL communicator (smcmc_comm_init / "
                          "smcmc_allreduce_moments, the C / C++ callers' path) instead of torch.distributed")
     args = ap.parse_args()
+    if args.config == "c4":
+        # the defaults of config 4 where the command line left the config-2 ones
+        if args.dim == DIM: args.dim = 500
+        if args.chains == CHAINS_PER_GPU: args.chains = 32768
 
     import torch
     from smcmc_amd_loader import load_package
@@ -375,6 +380,13 @@ def main():
         # the size of the communicator the moments crossed: the library's own (ncclCommCount) or torch's RCCL group
         rccl_ranks = eng.comm_ranks() if args.native_comm else dist.get_world_size()
     ms_allreduce = (float(np.mean([a.elapsed_time(b) for a, b in backend.comm_events])) if backend.comm_events else None)
+    kernel_ms_per_rank = None
+    if world > 1:
+        # every rank's device time per window of step launches (HIP events on its stream)
+        mine = torch.zeros(world, dtype=torch.float64, device="cpu" if args.native_comm else "cuda")
+        mine[rank] = float(np.mean([a.elapsed_time(b) for a, b in backend.events]))
+        dist.all_reduce(mine, op=dist.ReduceOp.SUM)
+        kernel_ms_per_rank = [float(v) for v in mine.cpu()]
 
     chain_steps = float(args.chains) * world * args.window * args.steps
     value = chain_steps / dt
@@ -399,7 +411,7 @@ def main():
     # (definition of MakeAutocorrelation.C:127-148) pooled over all chains, Geyer's
     # initial positive sequence, minimum over dimensions.
     ess_per_chain_step = None
-    if rank == 0 and not args.no_ess:
+    if rank == 0 and not args.no_ess and dim <= 63:   # (the trace of a D = 500 ensemble would not fit)
         try:
             ess_per_chain_step = measure_ess(eng, torch, dim)
         except Exception as exc:   # a diagnostic, never a reason to lose the bench line
@@ -411,16 +423,22 @@ def main():
         "metric": "chain-steps/s on D=50 TDummyLogLikelihood, 65 536 chains; ESS/s + accept rate",
         "value": value, "unit": "chain-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "rccl_ranks": rccl_ranks, "ms_allreduce": ms_allreduce,
+        "rccl_ranks": rccl_ranks, "ms_allreduce": ms_allreduce, "kernel_ms_per_rank": kernel_ms_per_rank,
         "comm": ("none (one rank)" if world == 1 else "library RCCL communicator (smcmc_comm_init / smcmc_allreduce_moments)"
                  if args.native_comm else "torch.distributed nccl (= RCCL)"),
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": ("TDummyLogLikelihood header form (quadratic form)" if args.header_tdummy else
+        "rng": "philox4x32-7 (counter-based, key = seed, counter = (block, global chain id, step, stream); "
+               "include/smcmc_detmath.h SMCMC_PHILOX_ROUNDS)",
+        "config": {"workload": ("BASELINE config 4: " if args.config == "c4" else "") +
+                               ("TDummyLogLikelihood header form (quadratic form)" if args.header_tdummy else
                                 "TDummyLogLikelihood README form (iso-Gaussian)") +
-                               " D=%d, %d chains/GPU, TProposeAdaptiveStep pooled covariance, window=%d steps/launch"
-                               % (dim, args.chains, args.window),
+                               " D=%d, %d chains/GPU%s, TProposeAdaptiveStep pooled covariance, window=%d steps/launch"
+                               % (dim, args.chains, (" (%d chains sharded over %d GPUs, one all-reduce of the pooled moments "
+                                                     "per window)" % (args.chains * world, world)) if args.config == "c4" else "",
+                                  args.window),
+                   "baseline_config": 4 if args.config == "c4" else 2,
                    "dim": dim, "mode": "frozen" if args.frozen else "pooled", "chains_per_gpu": args.chains, "window": args.window,
-                   "arithmetic": "fused" if args.fast else "reference-order", "seed": 20240607},
+                   "arithmetic": "fused" if args.fast else "reference-order", "seed": 20240607, "rng": "philox4x32-7"},
         "accept_rate": float(naccept.sum() / (total_steps * args.chains)),
         "ess_per_chain_step": ess_per_chain_step,
         "ess_per_s": (ess_per_chain_step * value) if ess_per_chain_step else None,
@@ -441,13 +459,14 @@ def main():
                                        "instruction's shadow (profiles/r03_notes.md, tools/micro/pipe_overlap.hip)",
                      "limiter": "instruction issue of a lone wavefront per SIMD; see profiles/r03_notes.md",
                      "algorithmic_bytes_per_launch": per_launch * bytes_cs,
-                     "kernel": "step_kernel<%d,%s,%s,tri,moments>" % (dim, "QUADFORM" if args.header_tdummy else "ISO",
-                                                                           "fused" if args.fast else "exact"),
+                     "kernel": ("step_kernel<%d,%s,%s,tri,moments>" % (dim, "QUADFORM" if args.header_tdummy else "ISO",
+                                                                            "fused" if args.fast else "exact")) if dim <= 63 else
+                               ("panel_mfma_kernel + fold_ring_kernel" if args.fast else "panel_step_kernel + fold_ring_kernel"),
                      "kernel_ms": kms, "bytes_per_chain_step": bytes_cs, "flops_per_chain_step": flops_cs,
                      "chain_steps_per_launch": per_launch},
     }
     eng.close()
-    if rank == 0 and world == 1 and not args.no_extras:
+    if rank == 0 and world == 1 and not args.no_extras and args.config == "c2":
         extra = {}
         rng = np.random.default_rng(0)
         try:
@@ -482,7 +501,7 @@ def main():
             extra["c4_share_d500_32768_pooled_header_tdummy"] = extra_metropolis(
                 pkg, torch, stream, "TDummyLogLikelihood header form D=500, 32 768 chains, pooled (the likelihood config 4 "
                 "names, in the reference's order: one serial D^2-term sum per chain)", 500, 32768, "quadform",
-                pkg.LIKE_QUADFORM, tdummy_error(500), np.zeros(500), True, 1, dense_quadform=True)
+                pkg.LIKE_QUADFORM, tdummy_error(500), np.zeros(500), True, 1, dense_quadform=True, adapt_windows=1)
             extra["c4_share_d500_32768_pooled_header_tdummy_sparse_walk"] = extra_metropolis(
                 pkg, torch, stream, "TDummyLogLikelihood header form D=500, 32 768 chains, pooled, reference order; the serial "
                 "sum walks the 502 non-zero entries of Error", 500, 32768, "quadform",
@@ -490,13 +509,22 @@ def main():
             extra["c4_share_d500_32768_pooled_header_tdummy_fused"] = extra_metropolis(
                 pkg, torch, stream, "TDummyLogLikelihood header form D=500, 32 768 chains, pooled", 500, 32768, "quadform",
                 pkg.LIKE_QUADFORM, tdummy_error(500), np.zeros(500), False, 5)
-            extra["c5_hmc_d500_8192_L20"] = extra_hmc(pkg, torch, stream, 500, 8192, 20, True, 3, True)
-            extra["c5_hmc_d500_8192_L20_fused"] = extra_hmc(pkg, torch, stream, 500, 8192, 20, False, 10, True)
-            # the sampler rows: a burn-in in which the chains accept, then 200 trajectories timed
-            extra["c5_hmc_d500_8192_L20_tuned_sampler_diag_target_fused"] = extra_hmc(
-                pkg, torch, stream, 500, 8192, 20, False, 200, True, burn=300, ess=True, diagonal=True)
+            # config 5.  The sampler rows first: a burn-in in which the chains accept, then 200 trajectories timed, ESS from
+            # a 256-trajectory device trace.  Fixed step (SetMeanEpsilon(< 0) + SetLeapFrog(20)) on the target config 5
+            # names, in both arithmetic orders; the reference's own tuning on a target it can tune.
             extra["c5_hmc_d500_8192_L20_fixed_step_fused"] = extra_hmc(pkg, torch, stream, 500, 8192, 20, False, 200, False,
                                                                        burn=100, ess=True)
+            extra["c5_hmc_d500_8192_L20_fixed_step"] = extra_hmc(pkg, torch, stream, 500, 8192, 20, True, 100, False, burn=100)
+            extra["c5_hmc_d500_8192_L20_tuned_sampler_diag_target_fused"] = extra_hmc(
+                pkg, torch, stream, 500, 8192, 20, False, 200, True, burn=300, ess=True, diagonal=True)
+            # As the reference tunes it: from its start value 0.05 on the header form's rho = 0.999999 pair every
+            # trajectory is rejected and UpdateErrorMatrix never sets a step below 0.5 x 0.01 (TSimpleHMC.H:825-839) -- the
+            # chains stand still, bit for bit as the CPU restatement does.  Throughput rows of that path, nothing more.
+            extra["c5_as_reference_tunes"] = {
+                "note": "accept_rate 0: the reference's own tuning fails on this target (2.5 x its stability limit); kept as "
+                        "the timing of the adaptive path (covariance fold + pooled UpdateErrorMatrix every step)",
+                "c5_hmc_d500_8192_L20": extra_hmc(pkg, torch, stream, 500, 8192, 20, True, 100, True),
+                "c5_hmc_d500_8192_L20_fused": extra_hmc(pkg, torch, stream, 500, 8192, 20, False, 100, True)}
         except Exception as exc:   # never a reason to lose the headline
             extra["error"] = repr(exc)
         out["extra"] = extra

@@ -332,6 +332,8 @@ int smcmc_hmc_sync(smcmc_hmc* h);                                        /* the 
  * buffer: the caller adds the ranks' vectors, e.g. one RCCL all-reduce), apply (UpdateCovariance fed with the batch, then
  * UpdateErrorMatrix, the same on every rank).  Set the sync interval beyond the steps of a window and call these at its
  * end; smcmc_hmc_sync = reduce + apply. */
+/* (one reduction at a time: a second reduce -- explicit, or the sync a step triggers when the interval runs out --
+ * before the apply of the first is SMCMC_ERR_LOGIC; a sharded run sets the interval beyond its window and syncs itself) */
 int smcmc_hmc_moments_size(const smcmc_hmc* h);
 int smcmc_hmc_reduce_moments(smcmc_hmc* h);
 int smcmc_hmc_export_moments(smcmc_hmc* h, double* dst_device);
@@ -345,6 +347,10 @@ int smcmc_hmc_get_covariance(smcmc_hmc* h, double* out);                 /* GetE
 int smcmc_hmc_start(smcmc_hmc* h, const double* x0, int broadcast);      /* Start :210-269 */
 int smcmc_hmc_step(smcmc_hmc* h, int nsteps);                            /* nsteps x Step(false) :279-401 */
 int smcmc_hmc_read_state(smcmc_hmc* h, double* q, double* momentum, double* logl);   /* fAccepted, fAcceptedMomentum */
+/* fAccepted of every chain into a DEVICE buffer [dim][smcmc_hmc_nchains_padded] (one slot of a trace for
+ * smcmc_autocorrelation_sums), on the engine's stream: what SimpleHMC.C:51-66 fills its tree with, without the trip to the host. */
+int smcmc_hmc_copy_positions(smcmc_hmc* h, double* dst_device);
+int smcmc_hmc_nchains_padded(const smcmc_hmc* h);
 int smcmc_hmc_read_lane_f64(smcmc_hmc* h, int field, double* out);
 int smcmc_hmc_read_lane_i32(smcmc_hmc* h, int field, int32_t* out);
 

@@ -59,8 +59,9 @@ SMCMC_HD double smcmc_u2d(uint64_t x) {
     union { double d; uint64_t u; } v; v.u = x; return v.d;
 }
 
-/* ---- Philox4x32-10 (Salmon et al., SC'11; Random123 reference vectors in
- * tests/test_detmath.py) ------------------------------------------------ */
+/* ---- Philox4x32 (Salmon et al., SC'11): the round function and key schedule, for any number of rounds.  The engine
+ * draws with SMCMC_PHILOX_ROUNDS = 7 of them (smcmc_draw_block below); the 10-round generator of the paper is here for
+ * the Random123 reference vectors of tests/test_detmath.py, which pin both. ------------------------------------- */
 #define SMCMC_PHILOX_M0 0xD2511F53u
 #define SMCMC_PHILOX_M1 0xCD9E8D57u
 #define SMCMC_PHILOX_W0 0x9E3779B9u

@@ -132,6 +132,8 @@ SIGNATURES = {
     "smcmc_hmc_start": (C.c_int, [_H, _dp, C.c_int]),
     "smcmc_hmc_step": (C.c_int, [_H, C.c_int]),
     "smcmc_hmc_read_state": (C.c_int, [_H, _dp, _dp, _dp]),
+    "smcmc_hmc_copy_positions": (C.c_int, [_H, C.c_void_p]),
+    "smcmc_hmc_nchains_padded": (C.c_int, [_H]),
     "smcmc_hmc_read_lane_f64": (C.c_int, [_H, C.c_int, _dp]),
     "smcmc_hmc_read_lane_i32": (C.c_int, [_H, C.c_int, _ip]),
     "smcmc_vaat_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint32, C.c_int, C.POINTER(_H)]),

@@ -325,6 +325,10 @@ int hmc_pull(smcmc_hmc* h) {
 // The moment groups of the steps since the last update summed (in group order) into the packed vector M, which is what
 // crosses ranks when the ensemble is sharded (smcmc_hmc_export_moments / import).
 int hmc_reduce(smcmc_hmc* h) {
+    // d_moments holds ONE reduction: a second one (an explicit smcmc_hmc_reduce_moments, or the sync a step triggers
+    // between a caller's reduce / import and its apply) would overwrite moments that no update has absorbed yet
+    if (h->steps_reduced > 0)
+        return hfail(h, SMCMC_ERR_LOGIC, "moments of an earlier smcmc_hmc_reduce_moments are waiting for smcmc_hmc_apply_moments");
     h->steps_reduced += h->steps_in_window;
     h->steps_in_window = 0;
     hipError_t e = launch_fold_reduce(h->d_gacc, h->dim, h->fold_nslices, h->d_moments, h->stream);
@@ -784,6 +788,15 @@ int smcmc_hmc_read_state(smcmc_hmc* h, double* q, double* momentum, double* logl
                                    hipMemcpyDeviceToHost));
     return SMCMC_OK;
 }
+
+int smcmc_hmc_copy_positions(smcmc_hmc* h, double* dst_device) {
+    if (!h || !dst_device || !h->started) return SMCMC_ERR_INVALID;
+    HMC_ON_DEVICE(h);
+    HMC_TRY(h, hipMemcpyAsync(dst_device, h->d_q, sizeof(double) * (size_t)h->dim * h->npad, hipMemcpyDeviceToDevice, h->stream));
+    return SMCMC_OK;
+}
+
+int smcmc_hmc_nchains_padded(const smcmc_hmc* h) { return h ? h->npad : 0; }
 
 int smcmc_hmc_read_lane_f64(smcmc_hmc* h, int field, double* out) {
     if (!h || !out || field < 0 || field >= SMCMC_LANE_F64_COUNT_) return SMCMC_ERR_INVALID;

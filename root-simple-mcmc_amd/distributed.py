@@ -53,6 +53,26 @@ class HipBackend:
         self.engine.apply_moments()
 
 
+class HmcBackend:
+    """Adapter for the HMC engine (config 5 sharded): `window` trajectories of every local chain with the covariance
+    fold running, then the pooled UpdateCovariance / UpdateErrorMatrix on the all-reduced moments
+    (smcmc_hmc_reduce_moments / export / import / apply).  The engine's own sync interval is set beyond any window, so
+    the only updates are the ones run_windows makes -- on every rank the same update of the same bits."""
+
+    def __init__(self, engine, time_steps=False, stream=None):
+        import torch
+        self.engine = engine
+        self.frozen = False
+        engine.SetSyncInterval(1 << 30)
+        self.buffer = torch.zeros(engine.moments_size, dtype=torch.float64, device="cuda")
+        self.time_steps, self.stream, self.events, self.comm_events = time_steps, stream, [], []
+
+    step = HipBackend.step
+    moments_out = HipBackend.moments_out
+    local_update = HipBackend.local_update
+    moments_in = HipBackend.moments_in
+
+
 class NativeBackend:
     """The same window loop with the exchange inside the C library: smcmc_comm_init attaches an RCCL communicator to the
     engine (include/smcmc.h) and the all-reduce of the moments is ncclAllReduce on the engine's stream -- the path a C++

@@ -578,6 +578,23 @@ class HmcEngine:
         self._check(self._lib.smcmc_hmc_read_state(self._h, _ptr(q), _ptr(m), _ptr(logl)))
         return q, m, logl
 
+    @property
+    def nchains_padded(self): return self._lib.smcmc_hmc_nchains_padded(self._h)
+
+    def copy_positions(self, dst_device_ptr):
+        """fAccepted of every chain into a device buffer [dim][nchains_padded] (one slot of a trace), on the engine's stream."""
+        self._check(self._lib.smcmc_hmc_copy_positions(self._h, C.c_void_p(int(dst_device_ptr))))
+
+    def AutocorrelationSums(self, trace_ptr, nslots, centre=None, stream=0):
+        """As Engine.AutocorrelationSums, over a trace of copy_positions slots ([slot][dim][nchains_padded])."""
+        c = _f64(np.zeros(self.dim) if centre is None else centre)
+        s = np.zeros(self.dim)
+        lagged = np.zeros((_capi.AUTOCORR_LAGS, self.dim))
+        self._check(self._lib.smcmc_autocorrelation_sums(C.c_void_p(int(trace_ptr)), int(nslots), self.dim, self.dim,
+                                                         self.nchains, self.nchains_padded, _ptr(c), _ptr(s), _ptr(lagged),
+                                                         C.c_void_p(int(stream))))
+        return Autocorrelation(s, lagged, int(nslots), self.nchains)
+
     def lane(self, name):
         if name in _capi.HMC_LANE_F64:
             out = np.zeros(self.nchains)

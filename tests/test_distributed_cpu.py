@@ -37,7 +37,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, nchains=NCHAINS):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -46,7 +46,7 @@ def _worker(rank, world, port, out_dir):
     from smcmc_amd_loader import load_package
     pkg = load_package()
     from root_simple_mcmc_amd import distributed as D
-    first, count = D.shard(NCHAINS, rank, world)
+    first, count = D.shard(nchains, rank, world)
     ens = O.Ensemble(count, DIM, chain_offset=first, mode=O.MODE_POOLED)
     assert ens.start(np.zeros(DIM))
     D.run_windows(OracleBackend(ens), NWIN, WINDOW)
@@ -87,3 +87,24 @@ def test_two_ranks_equal_one_process(oracle, smcmc, tmp_path):
     assert np.array_equal(np.concatenate([r0["x"], r1["x"]], axis=1), whole.x)
     assert np.array_equal(r0["u"], whole.decomposition)
     assert np.array_equal(np.concatenate([r0["sigma"], r1["sigma"]]), whole.lane("sigma"))
+
+
+def test_four_ranks_with_an_uneven_last_shard(oracle, smcmc, tmp_path):
+    """world_size 4, 232 chains: shards of 64, 64, 64 and 40 (the last rank's group is ragged).  Every rank ends with the
+    bit-identical pooled proposal; against the unsharded ensemble the moments are the same sums added in another order
+    (gloo's ring instead of the single process's group order), so that comparison carries a rounding tolerance."""
+    world, total = 4, 232
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), total), nprocs=world, join=True)
+    r = [np.load(tmp_path / f"rank{k}.npz") for k in range(world)]
+    assert [int(x["count"]) for x in r] == [64, 64, 64, 40]
+    for x in r[1:]:
+        assert np.array_equal(x["u"], r[0]["u"]) and np.array_equal(x["cov"], r[0]["cov"])
+    from root_simple_mcmc_amd import distributed as D
+    whole = oracle.Ensemble(total, DIM, mode=oracle.MODE_POOLED)
+    assert whole.start(np.zeros(DIM))
+    D.run_windows(OracleBackend(whole), NWIN, WINDOW)
+    whole.step(3)
+    assert np.allclose(r[0]["u"], whole.decomposition, rtol=1e-11, atol=1e-13)
+    x = np.concatenate([k["x"] for k in r], axis=1)
+    assert x.shape == whole.x.shape
+    assert np.allclose(x, whole.x, rtol=1e-9, atol=1e-11)

@@ -389,3 +389,46 @@ def test_hmc_targets_without_a_gradient(gpu, oracle, kind, dim, gtype):
     with pytest.raises(gpu.SmcmcError) as err:
         e.Step(1, gradient_type=0)                               # the functor has no gradient: the reference throws
     assert err.value.status == 3
+
+
+def test_hmc_backend_exchange_and_the_pending_guard(gpu):
+    """distributed.HmcBackend (what run_windows drives for a sharded config 5): two engines with chain offsets exchanging
+    their window moments through the backend are one engine syncing at the same interval; and a second reduction before
+    the apply of the first is refused (SMCMC_ERR_LOGIC) instead of silently dropping a window's moments."""
+    import torch
+    from root_simple_mcmc_amd import distributed as D
+    dim, n, window = 24, 2048, 3
+    whole = gpu.HmcEngine(dim, n, seed=9)
+    whole.SetSyncInterval(window)
+    halves = [gpu.HmcEngine(dim, n // 2, seed=9, chain_offset=k * (n // 2)) for k in range(2)]
+    x0 = np.full(dim, 0.3)
+    whole.Start(x0)
+    backs = []
+    for h in halves:
+        backs.append(D.HmcBackend(h))
+        h.Start(x0)
+    for _ in range(5):
+        whole.Step(window)
+        outs = []
+        for b in backs:
+            b.step(window)
+            outs.append(b.moments_out().clone())
+        total = outs[0] + outs[1]                       # the all-reduce
+        for b in backs:
+            b.moments_in(total)
+        torch.cuda.synchronize()
+        q, m, _ = whole.state()
+        for k, h in enumerate(halves):
+            sl = slice(k * (n // 2), (k + 1) * (n // 2))
+            hq, hm, _ = h.state()
+            assert np.array_equal(hq, q[:, sl]) and np.array_equal(hm, m[:, sl])
+            assert np.array_equal(h.covariance, whole.covariance) and h.tuning == whole.tuning
+    h = halves[0]
+    h.Step(1)
+    h.reduce_moments()
+    h.Step(1)
+    with pytest.raises(gpu.SmcmcError) as err:
+        h.reduce_moments()
+    assert err.value.status == 2                        # SMCMC_ERR_LOGIC
+    h.apply_moments()
+    h.reduce_moments(); h.apply_moments()

@@ -115,6 +115,13 @@ typedef enum {
                                          * of the reference-order kernels and of SMCMC_MODE_PER_CHAIN walk its non-zero entries only --
                                          * bit for bit the dense sum (a skipped term is +-0), dense again for a non-finite point.
                                          * Reads back 1 whenever the dense sum is what runs. */
+    SMCMC_P_PERCHAIN_WAVE = 25,         /* SMCMC_MODE_PER_CHAIN: which kernel steps the chains.  1: one chain per WAVEFRONT (the chain's
+                                         * covariance in registers, its decomposition in LDS for a whole launch: the kernel for few
+                                         * chains, down to the single chain of SimpleMCMC.C); 0: one chain per lane (its O(D^2) state
+                                         * streamed through HBM every step); -1 (default): per wavefront wherever the likelihood
+                                         * is one it serves.  Same images, same bits either way; the likelihoods of
+                                         * the stress tests (ASYM, HORRIFIC, CONSTRAINED) always run one chain per lane.  Reads back
+                                         * what runs. */
     SMCMC_P_COUNT_
 } smcmc_param;
 
@@ -218,6 +225,19 @@ int smcmc_step(smcmc_engine* h, int nsteps, int metropolis);
  * log-likelihood (the `Accepted` / `LogLikelihood` branches, TSimpleMCMC.H:208-210)
  * into caller-owned DEVICE buffers save_x[slot][dim_padded][nchains_padded] (rows
  * >= dim are zero), save_logl[slot][nchains_padded]; slots = nsteps / stride. */
+/* nsteps x Step(false, metropolis) in one launch with a per-step record of one chain on the host: after every step
+ * what TSimpleMCMC::Step() leaves in its members and SaveStep() reads -- records[step * smcmc_record_stride()]:
+ * [0, dim) fAccepted, [dim, 2 dim) fProposed, then the scalars of smcmc_record_field.  SMCMC_MODE_PER_CHAIN with the
+ * one-chain-per-wavefront kernel (SMCMC_P_PERCHAIN_WAVE); SMCMC_ERR_UNSUPPORTED otherwise.  include/TSimpleMCMC_amd.H
+ * runs Step() ahead with it (TSimpleMCMC.H:370-496 one call at a time is one launch and three read-backs per step). */
+typedef enum {
+    SMCMC_REC_LOGL = 0, SMCMC_REC_LOGL_PROPOSED, SMCMC_REC_STEP_RMS, SMCMC_REC_LAST_ACCEPT, SMCMC_REC_TRIALS,
+    SMCMC_REC_SUCCESSES, SMCMC_REC_NEXT_UPDATE, SMCMC_REC_ACCEPTANCE, SMCMC_REC_ACCEPTANCE_TRIALS, SMCMC_REC_SIGMA,
+    SMCMC_REC_CENTER_TRIALS, SMCMC_REC_COVARIANCE_TRIALS, SMCMC_REC_COVARIANCE_TRACE, SMCMC_REC_TOTAL_STEPS,
+    SMCMC_REC_UPDATE_STATUS, SMCMC_REC_COUNT_
+} smcmc_record_field;
+int smcmc_record_stride(const smcmc_engine* h);      /* 2 dim + SMCMC_REC_COUNT_ */
+int smcmc_step_recorded(smcmc_engine* h, int nsteps, int metropolis, int chain, double* records);
 int smcmc_step_save(smcmc_engine* h, int nsteps, int metropolis, int stride,
                     double* save_x_device, double* save_logl_device);
 /* ForceStep (TSimpleMCMC.H:811-817): the next step of every chain proposes

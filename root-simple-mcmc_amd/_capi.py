@@ -20,8 +20,11 @@ PARAMS = ["COVARIANCE_WINDOW", "COVARIANCE_DEWEIGHT", "ACCEPTANCE_WINDOW", "ACCE
           "ACCEPTANCE_RIGIDITY", "TARGET_ACCEPTANCE", "SIGMA", "MAXIMUM_CORRELATION", "STEP_RMS_WINDOW",
           "NEXT_UPDATE", "COVARIANCE_TRIALS", "CENTER_TRIALS", "COVARIANCE_TRACE", "TOTAL_STEPS",
           "SIGMA_TRACE", "UPDATE_COUNT", "LAST_UPDATE_PATH", "EXACT_ARITHMETIC", "MOMENT_STRIDE", "MOMENT_GROUP", "KEEP_PROPOSED",
-          "DEVICE_UPDATE", "OVERLAP_UPDATE", "COVARIANCE_FROZEN", "DENSE_QUADFORM"]
+          "DEVICE_UPDATE", "OVERLAP_UPDATE", "COVARIANCE_FROZEN", "DENSE_QUADFORM", "PERCHAIN_WAVE"]
 P = {name: i for i, name in enumerate(PARAMS)}
+RECORD_FIELDS = ["logl", "logl_proposed", "step_rms", "last_accept", "trials", "successes", "next_update", "acceptance",
+                 "acceptance_trials", "sigma", "center_trials", "covariance_trials", "covariance_trace", "total_steps",
+                 "update_status"]   # smcmc_record_field
 LANE_F64 = {name: i for i, name in enumerate(
     ["logl", "sigma", "acceptance", "acceptance_trials", "rigidity", "last_value", "last_x0", "step_rms",
      "logl_proposed", "center_trials", "covariance_trials", "sigma_trace"])}
@@ -75,6 +78,8 @@ SIGNATURES = {
     "smcmc_restore": (C.c_int, [_H, _dp, C.c_int, C.POINTER(SavedState)]),
     "smcmc_step": (C.c_int, [_H, C.c_int, C.c_int]),
     "smcmc_step_save": (C.c_int, [_H, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "smcmc_record_stride": (C.c_int, [_H]),
+    "smcmc_step_recorded": (C.c_int, [_H, C.c_int, C.c_int, C.c_int, _dp]),
     "smcmc_force_step": (C.c_int, [_H, _dp, C.c_int]),
     "smcmc_reduce_moments": (C.c_int, [_H]),
     "smcmc_moments_size": (C.c_int, [_H]),

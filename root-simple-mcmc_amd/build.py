@@ -53,6 +53,7 @@ def _units(user_flag=None):
              hmc, ("smcmc_hmc_mfma_inst.hip", [], "hmc_mfma"),
              vaat, ("smcmc_vaat_large.hip", [], "vaat_large"),
              ("smcmc_pooled_update.hip", [], "pooled_update"), ("smcmc_perchain_inst.hip", [], "perchain"),
+             ("smcmc_perchain_wave_inst.hip", [], "perchain_wave"),
              ("smcmc_panel_mfma_inst.hip", [], "panel_mfma"), ("smcmc_fold_inst.hip", [], "fold")]
     for dp in dp_list():
         for like in LIKELIHOODS:

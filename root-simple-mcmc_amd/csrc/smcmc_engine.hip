@@ -22,6 +22,7 @@
 #include "smcmc_pooled_update.hip.h"
 #include "smcmc_fold_ring.hip.h"
 #include "smcmc_perchain_kernel.hip.h"
+#include "smcmc_perchain_wave.hip.h"
 #include "smcmc_proposal.hpp"
 
 using namespace smcmc;
@@ -138,6 +139,10 @@ struct smcmc_engine {
     double* d_pc_tmpl = nullptr;   // what the host hands to every chain at Start / Restore / ResetProposal: cov packed, then ut
     int* d_pc_flag = nullptr;      // chains that stopped for the host's fallback ladder in the latest launch
     bool pc_frozen = false;        // SMCMC_P_COVARIANCE_FROZEN
+    int pc_wave = -1;              // SMCMC_P_PERCHAIN_WAVE: -1 automatic, 0 / 1 one chain per lane / per wavefront
+    smcmc::PerChainRecord pc_rec = {nullptr, 0, 0};   // the per-step record of the launch in progress (smcmc_step_recorded)
+    double* d_pc_rec = nullptr;    // its device buffer
+    size_t pc_rec_cap = 0;         // ... and capacity in doubles
     std::string error;
 };
 
@@ -659,6 +664,7 @@ int ensure_ring(smcmc_engine* h) {
         hipMalloc(&h->d_ring_logl, sizeof(double) * (size_t)h->npad * steps) != hipSuccess) {
         (void)hipGetLastError();
         (void)hipFree(h->d_ring); (void)hipFree(h->d_ring_logl);
+    (void)hipFree(h->d_pc_rec);
     smcmc::fold_ring_release(h->fold);
         h->d_ring = nullptr; h->d_ring_logl = nullptr;
         h->ring_steps = 0;
@@ -860,9 +866,21 @@ PerChainParams pc_params(smcmc_engine* h, const StepParams& p) {
 
 // Launches until every chain has reached the target step: a chain whose decomposition failed waits for the host's
 // ladder and catches up in the next launch (its draws are keyed on its own step count).
+// One chain per wavefront (smcmc_perchain_wave.hip.h) where an ensemble is too small to fill the chip with one chain per
+// lane; the two kernels share every image, so the choice can change from launch to launch.
+bool pc_use_wave(const smcmc_engine* h) {
+    if (!smcmc::perchain_wave_serves(h->likelihood)) return false;
+    if (h->pc_wave >= 0) return h->pc_wave != 0;
+    return true;     // measured faster at every ensemble size, 1 to 65 536 chains (profiles/r04_notes.md)
+}
+
 int pc_run(smcmc_engine* h, PerChainParams q) {
+    const bool wave = pc_use_wave(h);
+    if (h->pc_rec.rec && !wave)
+        return fail(h, SMCMC_ERR_UNSUPPORTED, "a per-step record needs the one-chain-per-wavefront kernel (SMCMC_P_PERCHAIN_WAVE)");
     for (int round = 0; round < 1000; ++round) {
-        const hipError_t e = launch_perchain(q, h->likelihood, h->stream);
+        const hipError_t e = wave ? smcmc::launch_perchain_wave(q, h->pc_rec, h->likelihood, h->stream)
+                                  : launch_perchain(q, h->likelihood, h->stream);
         if (e != hipSuccess) return fail(h, SMCMC_ERR_HIP, std::string("per-chain kernel launch: ") + hipGetErrorString(e));
         int flagged = 0;
         HIP_TRY(h, hipMemcpyAsync(&flagged, h->d_pc_flag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
@@ -1358,6 +1376,7 @@ int smcmc_set_param(smcmc_engine* h, int which, double v) {
             P.centreTrials = v;
             return (per_chain(h) && h->started) ? broadcast_lane_f64(h, SMCMC_LANE_CENTER_TRIALS, v) : SMCMC_OK;
         case SMCMC_P_COVARIANCE_FROZEN: h->pc_frozen = (v != 0.0); return SMCMC_OK;
+        case SMCMC_P_PERCHAIN_WAVE: h->pc_wave = (v < 0.0) ? -1 : (v != 0.0 ? 1 : 0); return SMCMC_OK;
         case SMCMC_P_DENSE_QUADFORM:
             h->dense_quadform = (v != 0.0);
             return (h->started && h->likelihood == SMCMC_LIKE_QUADFORM) ? upload_like_csr(h) : SMCMC_OK;
@@ -1471,6 +1490,7 @@ int smcmc_get_param(smcmc_engine* h, int which, double* out) {
         case SMCMC_P_OVERLAP_UPDATE: *out = h->overlap_update ? 1.0 : 0.0; break;
         case SMCMC_P_COVARIANCE_FROZEN: *out = (h->pc_frozen || h->mode == SMCMC_MODE_FROZEN) ? 1.0 : 0.0; break;
         case SMCMC_P_DENSE_QUADFORM: *out = (h->dense_quadform || h->d_like_rowptr == nullptr) ? 1.0 : 0.0; break;
+        case SMCMC_P_PERCHAIN_WAVE: *out = (per_chain(h) && h->dim <= kPcMaxDim && pc_use_wave(h)) ? 1.0 : 0.0; break;
         default: return fail(h, SMCMC_ERR_INVALID, "unknown parameter");
     }
     return SMCMC_OK;
@@ -1670,6 +1690,31 @@ int smcmc_step(smcmc_engine* h, int nsteps, int metropolis) {
 int smcmc_step_save(smcmc_engine* h, int nsteps, int metropolis, int stride, double* save_x, double* save_logl) {
     if (!save_x || !save_logl) return fail(h, SMCMC_ERR_INVALID, "save buffers must be device pointers");
     return launch(h, nsteps, metropolis, stride, save_x, save_logl);
+}
+
+int smcmc_record_stride(const smcmc_engine* h) { return h ? 2 * h->dim + smcmc::kPcRecScalars : 0; }
+
+int smcmc_step_recorded(smcmc_engine* h, int nsteps, int metropolis, int chain, double* records) {
+    if (!h || !records) return SMCMC_ERR_INVALID;
+    ON_DEVICE(h);
+    if (nsteps <= 0) return SMCMC_OK;
+    if (!per_chain(h)) return fail(h, SMCMC_ERR_UNSUPPORTED, "smcmc_step_recorded serves SMCMC_MODE_PER_CHAIN");
+    if (chain < 0 || chain >= h->nchains) return fail(h, SMCMC_ERR_INVALID, "no such chain");
+    const int stride = smcmc_record_stride(h);
+    const size_t need = (size_t)nsteps * stride;
+    if (need > h->pc_rec_cap) {
+        (void)hipFree(h->d_pc_rec);
+        h->d_pc_rec = nullptr; h->pc_rec_cap = 0;
+        HIP_TRY(h, hipMalloc(&h->d_pc_rec, need * sizeof(double)));
+        h->pc_rec_cap = need;
+    }
+    h->pc_rec = smcmc::PerChainRecord{h->d_pc_rec, chain, stride};
+    const int st = launch(h, nsteps, metropolis, 1, nullptr, nullptr);
+    h->pc_rec = smcmc::PerChainRecord{nullptr, 0, 0};
+    if (st) return st;
+    HIP_TRY(h, hipMemcpyAsync(records, h->d_pc_rec, need * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SMCMC_OK;
 }
 
 int smcmc_force_step(smcmc_engine* h, const double* point, int broadcast) {

@@ -231,6 +231,17 @@ class Engine:
         """nsteps x Step(save=false, metropolis) of every chain, one launch."""
         self._check(self._lib.smcmc_step(self._h, int(nsteps), int(metropolis)))
 
+    def StepRecorded(self, nsteps, chain=0, metropolis=0):
+        """nsteps x Step(false) in one launch with the per-step record of one chain (smcmc_step_recorded): a dict of
+        arrays over the steps -- "accepted" / "proposed" [step][dim] and the scalars of smcmc_record_field."""
+        stride = self._lib.smcmc_record_stride(self._h)
+        rec = np.zeros((int(nsteps), stride))
+        self._check(self._lib.smcmc_step_recorded(self._h, int(nsteps), int(metropolis), int(chain), _ptr(rec)))
+        out = {"accepted": rec[:, :self.dim].copy(), "proposed": rec[:, self.dim:2 * self.dim].copy()}
+        for k, name in enumerate(_capi.RECORD_FIELDS):
+            out[name] = rec[:, 2 * self.dim + k].copy()
+        return out
+
     def StepSave(self, nsteps, save_x_ptr, save_logl_ptr, stride=1, metropolis=0):
         """As Step, also writing the accepted points into device buffers (raw pointers)."""
         self._check(self._lib.smcmc_step_save(self._h, int(nsteps), int(metropolis), int(stride),

@@ -14,6 +14,17 @@ I32 = {"trials": "trials", "successes": "successes", "next_update": "next_update
        "chain_steps": "total_steps", "update_count": "update_count", "last_update_path": "last_update_path"}
 
 
+KERNEL = {"wave": -1}
+
+
+@pytest.fixture(autouse=True, params=[0, 1], ids=["chain-per-lane", "chain-per-wavefront"])
+def which_kernel(request):
+    """Every test of the module runs on both kernels of the mode (SMCMC_P_PERCHAIN_WAVE): perchain_step_kernel and
+    perchain_wave_kernel share the images and must give the same bits -- oracle.Chain's."""
+    KERNEL["wave"] = request.param
+    yield request.param
+
+
 def _params(oracle, kind, dim):
     prm = oracle.like_params(kind, dim)
     return prm if prm.size else None
@@ -24,6 +35,9 @@ def _make(gpu, oracle, dim, n, kind=0, which=None, seed=20240607, offset=0, x0=N
     prm = _params(oracle, kind, dim)
     e = gpu.Engine(dim, n, likelihood=kind, likelihood_params=prm, seed=seed, chain_offset=offset,
                    mode=gpu.MODE_PER_CHAIN)
+    e.set_param("PERCHAIN_WAVE", KERNEL["wave"])
+    if kind in (0, 1, 2):
+        assert e.get_param("PERCHAIN_WAVE") == KERNEL["wave"]
     which = list(range(n)) if which is None else list(which)
     chains = {c: oracle.Chain(dim, kind=kind, params=prm, seed=seed, chain_id=offset + c) for c in which}
     if setup:
@@ -315,3 +329,36 @@ def test_the_full_ensemble_sampled_lanes(gpu, oracle):
     assert np.all(e.lane("update_count") >= 2)
     assert np.all(e.lane("chain_steps") == 400)
     e.close()
+
+
+def test_step_recorded_is_the_chain_step_by_step(gpu, oracle, which_kernel):
+    """smcmc_step_recorded: one launch of many steps leaves, for one chain, what TSimpleMCMC::Step() shows after EVERY
+    step -- fAccepted, fProposed, both likelihoods, StepRMS, the accept flag, the Adaptive* scalars and the covariance
+    trace SaveStep writes -- equal to oracle.Chain stepped one call at a time, UpdateProposal events included."""
+    dim, n, nsteps, c = 9, 5, 400, 3
+    e, chains = _make(gpu, oracle, dim, n, 0, which=(c,))
+    _both(e, chains, "SetNextUpdate", "set_next_update", 7)
+    if not which_kernel:
+        with pytest.raises(gpu.SmcmcError) as err:
+            e.StepRecorded(4, chain=c)
+        assert err.value.status == 5                                   # SMCMC_ERR_UNSUPPORTED: the record is the wave kernel's
+        return
+    rec = e.StepRecorded(nsteps, chain=c)
+    ch = chains[c]
+    names = {"logl": "accepted_logl", "logl_proposed": "proposed_logl", "step_rms": "step_rms", "trials": "trials",
+             "successes": "successes", "next_update": "next_update", "acceptance": "acceptance",
+             "acceptance_trials": "acceptance_trials", "sigma": "sigma", "center_trials": "central_trials",
+             "covariance_trials": "cov_trials", "total_steps": "total_steps"}
+    updates = 0
+    for s in range(nsteps):
+        moved = ch.step(False, 0)
+        sc = ch.scalars
+        assert np.array_equal(rec["accepted"][s], ch.accepted), f"step {s}: accepted"
+        assert np.array_equal(rec["proposed"][s], ch.proposed), f"step {s}: proposed"
+        assert bool(rec["last_accept"][s]) == bool(moved), f"step {s}: accept flag"
+        for k, ok in names.items():
+            assert rec[k][s] == sc[ok], f"step {s}: {k} = {rec[k][s]!r}, reference chain {sc[ok]!r}"
+        assert rec["covariance_trace"][s] == np.add.accumulate(np.diag(ch.covariance))[-1], f"step {s}: trace"
+        updates = int(sc["update_count"])
+    assert updates >= 2
+    _same(e, chains, "after the recorded launch")

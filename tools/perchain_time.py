@@ -31,6 +31,8 @@ def main():
     ap.add_argument("--frozen", action="store_true", help="SetCovarianceFrozen: the covariance stream is skipped")
     ap.add_argument("--header-tdummy", action="store_true",
                     help="the header form of TDummyLogLikelihood (quadratic form, TDummyLogLikelihood.H:24-28) instead of the README form")
+    ap.add_argument("--kernel", choices=("auto", "lane", "wave"), default="auto",
+                    help="SMCMC_P_PERCHAIN_WAVE: one chain per lane (perchain_step_kernel) or per wavefront (perchain_wave_kernel)")
     ap.add_argument("--json")
     a = ap.parse_args()
     import torch
@@ -45,6 +47,7 @@ def main():
             cov[0, a.dim - 1] = cov[a.dim - 1, 0] = 0.999999                     # TDummyLogLikelihood::Init(), :44-142
             kw = {"likelihood": pkg.LIKE_QUADFORM, "likelihood_params": np.linalg.inv(cov)}
         e = pkg.Engine(a.dim, n, mode=pkg.MODE_PER_CHAIN, stream=stream.cuda_stream, **kw)
+        e.set_param("PERCHAIN_WAVE", {"auto": -1, "lane": 0, "wave": 1}[a.kernel])
         if a.frozen:
             e.SetCovarianceFrozen(True)
         assert e.Start(np.zeros(a.dim))
@@ -60,7 +63,7 @@ def main():
         dt = time.perf_counter() - t0
         kms = float(np.mean([x.elapsed_time(y) for x, y in evs]))
         rate = n * a.steps / (kms * 1e-3)
-        rows.append({"dim": a.dim, "chains": n, "likelihood": "header TDummy" if a.header_tdummy else "README TDummy", "steps_per_launch": a.steps, "kernel_ms_per_launch": kms,
+        rows.append({"dim": a.dim, "chains": n, "kernel": "one chain per wavefront" if e.get_param("PERCHAIN_WAVE") else "one chain per lane", "likelihood": "header TDummy" if a.header_tdummy else "README TDummy", "steps_per_launch": a.steps, "kernel_ms_per_launch": kms,
                      "us_per_ensemble_step": kms * 1e3 / a.steps, "chain_steps_per_s": rate,
                      "wall_chain_steps_per_s": n * a.steps * a.launches / dt,
                      "algorithmic_bytes_per_chain_step": algorithmic_bytes(a.dim),

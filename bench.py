@@ -276,6 +276,33 @@ def extra_hmc(pkg, torch, stream, dim, chains, leapfrog, exact, steps, tuned, bu
     return out
 
 
+def cpp_step_loop(dim, cycles, steps, runahead, save=False):
+    """The unchanged caller: examples/StepLoop_amd.C (the loop of SimpleMCMC.C:176-243 over include/TSimpleMCMC_amd.H, one
+    chain, Step() one call at a time, the driver's getters and per-cycle UpdateProposal() + setters) compiled with g++ and
+    run as a child process; Step() calls per second of its timed loop."""
+    import subprocess
+    import tempfile
+    libdir = os.path.join(ROOT, "root-simple-mcmc_amd", "lib")
+    with tempfile.TemporaryDirectory() as tmp:
+        exe = os.path.join(tmp, "step_loop.exe")
+        cmd = ["g++", "-std=c++17", "-O2", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "StepLoop_amd.C"),
+               "-L" + libdir, "-lsmcmc_amd", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            return {"error": r.stderr[-400:]}
+        r = subprocess.run([exe, str(dim), str(cycles), str(steps), "1" if save else "0", "1" if runahead else "0"],
+                           capture_output=True, text=True, timeout=600)
+        if r.returncode != 0:
+            return {"error": (r.stdout + r.stderr)[-400:]}
+        words = r.stdout.split()
+        return {"workload": "SimpleMCMC.C:176-243 over TSimpleMCMC_amd.H: one chain, D=%d README-form TDummyLogLikelihood, per-chain "
+                            "adaptation, %d cycles x %d Step(%s) calls with the driver's prints, UpdateProposal() and setters per cycle"
+                            % (dim, cycles, steps, "true" if save else "false"),
+                "steps_per_s": float(words[words.index("steps_per_s") + 1]),
+                "step_runs_ahead": bool(int(words[words.index("run_ahead") + 1])),
+                "moved": int(words[words.index("moved") + 1])}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -525,6 +552,11 @@ def main():
                         "the timing of the adaptive path (covariance fold + pooled UpdateErrorMatrix every step)",
                 "c5_hmc_d500_8192_L20": extra_hmc(pkg, torch, stream, 500, 8192, 20, True, 100, True),
                 "c5_hmc_d500_8192_L20_fused": extra_hmc(pkg, torch, stream, 500, 8192, 20, False, 100, True)}
+            # the drop-in loop: Step() one call at a time from a C++ caller, beside cpu_baseline (the same loop on one host core)
+            extra["cpp_step_loop_d50"] = cpp_step_loop(50, 4, 20000, True)
+            extra["cpp_step_loop_d5"] = cpp_step_loop(5, 4, 50000, True)
+            extra["cpp_step_loop_d50_save_every_step"] = cpp_step_loop(50, 4, 20000, True, save=True)
+            extra["cpp_step_loop_d50_one_launch_per_call"] = cpp_step_loop(50, 1, 3000, False)
         except Exception as exc:   # never a reason to lose the headline
             extra["error"] = repr(exc)
         out["extra"] = extra

@@ -236,6 +236,14 @@ typedef enum {
     SMCMC_REC_CENTER_TRIALS, SMCMC_REC_COVARIANCE_TRIALS, SMCMC_REC_COVARIANCE_TRACE, SMCMC_REC_TOTAL_STEPS,
     SMCMC_REC_UPDATE_STATUS, SMCMC_REC_COUNT_
 } smcmc_record_field;
+/* smcmc_snapshot remembers the state of the whole ensemble on the device (points, per-chain scalars, every chain's
+ * centre / covariance / decomposition, the step count); smcmc_rollback returns to it, any number of times.  Draws are
+ * keyed on (chain, step), so stepping again from a snapshot repeats the same steps: TSimpleMCMC_amd.H's Step() runs
+ * ahead of its caller with smcmc_step_recorded and takes the steps it ran too far back this way when a setter,
+ * UpdateProposal() or SaveStep(true) needs the state AT the caller's step.  A started SMCMC_MODE_PER_CHAIN ensemble;
+ * settings changed in between (smcmc_set_param ...) are not part of the snapshot. */
+int smcmc_snapshot(smcmc_engine* h);
+int smcmc_rollback(smcmc_engine* h);
 int smcmc_record_stride(const smcmc_engine* h);      /* 2 dim + SMCMC_REC_COUNT_ */
 int smcmc_step_recorded(smcmc_engine* h, int nsteps, int metropolis, int chain, double* records);
 int smcmc_step_save(smcmc_engine* h, int nsteps, int metropolis, int stride,

@@ -78,6 +78,8 @@ SIGNATURES = {
     "smcmc_restore": (C.c_int, [_H, _dp, C.c_int, C.POINTER(SavedState)]),
     "smcmc_step": (C.c_int, [_H, C.c_int, C.c_int]),
     "smcmc_step_save": (C.c_int, [_H, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "smcmc_snapshot": (C.c_int, [_H]),
+    "smcmc_rollback": (C.c_int, [_H]),
     "smcmc_record_stride": (C.c_int, [_H]),
     "smcmc_step_recorded": (C.c_int, [_H, C.c_int, C.c_int, C.c_int, _dp]),
     "smcmc_force_step": (C.c_int, [_H, _dp, C.c_int]),

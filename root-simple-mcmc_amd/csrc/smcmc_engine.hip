@@ -142,6 +142,10 @@ struct smcmc_engine {
     int pc_wave = -1;              // SMCMC_P_PERCHAIN_WAVE: -1 automatic, 0 / 1 one chain per lane / per wavefront
     smcmc::PerChainRecord pc_rec = {nullptr, 0, 0};   // the per-step record of the launch in progress (smcmc_step_recorded)
     double* d_pc_rec = nullptr;    // its device buffer
+    // smcmc_snapshot / smcmc_rollback: a copy of the ensemble's state on the device (SMCMC_MODE_PER_CHAIN)
+    void* snap[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    uint32_t snap_total_steps = 0;
+    bool snap_valid = false, snap_has_forced = false;
     size_t pc_rec_cap = 0;         // ... and capacity in doubles
     std::string error;
 };
@@ -665,6 +669,7 @@ int ensure_ring(smcmc_engine* h) {
         (void)hipGetLastError();
         (void)hipFree(h->d_ring); (void)hipFree(h->d_ring_logl);
     (void)hipFree(h->d_pc_rec);
+    for (int k = 0; k < 8; ++k) (void)hipFree(h->snap[k]);
     smcmc::fold_ring_release(h->fold);
         h->d_ring = nullptr; h->d_ring_logl = nullptr;
         h->ring_steps = 0;
@@ -1690,6 +1695,56 @@ int smcmc_step(smcmc_engine* h, int nsteps, int metropolis) {
 int smcmc_step_save(smcmc_engine* h, int nsteps, int metropolis, int stride, double* save_x, double* save_logl) {
     if (!save_x || !save_logl) return fail(h, SMCMC_ERR_INVALID, "save buffers must be device pointers");
     return launch(h, nsteps, metropolis, stride, save_x, save_logl);
+}
+
+namespace {
+// the arrays that make up the state of a per-chain ensemble, and their sizes in bytes
+int snap_arrays(smcmc_engine* h, void* (&arr)[8], size_t (&bytes)[8]) {
+    const size_t NP = (size_t)h->npad, D = (size_t)h->dim, npk = D * (D + 1) / 2;
+    const size_t pad = (size_t)smcmc::kPcPad * smcmc::kWave;
+    arr[0] = h->d_x; bytes[0] = sizeof(double) * NP * h->dp;
+    arr[1] = h->d_lane_f64; bytes[1] = sizeof(double) * NP * SMCMC_LANE_F64_COUNT_;
+    arr[2] = h->d_lane_i32; bytes[2] = sizeof(int32_t) * NP * SMCMC_LANE_I32_COUNT_;
+    arr[3] = h->d_proposed; bytes[3] = sizeof(double) * NP * h->dp;
+    arr[4] = h->d_pc_cov; bytes[4] = sizeof(double) * (npk * NP + pad);
+    arr[5] = h->d_pc_ut; bytes[5] = sizeof(double) * (D * D * NP + pad);
+    arr[6] = h->d_pc_centre; bytes[6] = sizeof(double) * D * NP;
+    arr[7] = h->d_pc_last; bytes[7] = sizeof(double) * D * NP;
+    for (int k = 0; k < 8; ++k)
+        if (!arr[k]) return fail(h, SMCMC_ERR_LOGIC, "the ensemble has not been started in SMCMC_MODE_PER_CHAIN");
+    return SMCMC_OK;
+}
+}  // namespace
+
+int smcmc_snapshot(smcmc_engine* h) {
+    if (!h) return SMCMC_ERR_INVALID;
+    ON_DEVICE(h);
+    if (!per_chain(h) || !h->started) return fail(h, SMCMC_ERR_UNSUPPORTED, "smcmc_snapshot serves a started SMCMC_MODE_PER_CHAIN ensemble");
+    void* arr[8]; size_t bytes[8];
+    int st = snap_arrays(h, arr, bytes);
+    if (st) return st;
+    for (int k = 0; k < 8; ++k) {
+        if (!h->snap[k]) HIP_TRY(h, hipMalloc(&h->snap[k], bytes[k]));
+        HIP_TRY(h, hipMemcpyAsync(h->snap[k], arr[k], bytes[k], hipMemcpyDeviceToDevice, h->stream));
+    }
+    h->snap_total_steps = h->total_steps;
+    h->snap_has_forced = h->has_forced;
+    h->snap_valid = true;
+    return SMCMC_OK;
+}
+
+int smcmc_rollback(smcmc_engine* h) {
+    if (!h) return SMCMC_ERR_INVALID;
+    ON_DEVICE(h);
+    if (!h->snap_valid || !per_chain(h)) return fail(h, SMCMC_ERR_LOGIC, "no snapshot to return to");
+    void* arr[8]; size_t bytes[8];
+    int st = snap_arrays(h, arr, bytes);
+    if (st) return st;
+    for (int k = 0; k < 8; ++k)
+        HIP_TRY(h, hipMemcpyAsync(arr[k], h->snap[k], bytes[k], hipMemcpyDeviceToDevice, h->stream));
+    h->total_steps = h->snap_total_steps;
+    h->has_forced = h->snap_has_forced;
+    return SMCMC_OK;
 }
 
 int smcmc_record_stride(const smcmc_engine* h) { return h ? 2 * h->dim + smcmc::kPcRecScalars : 0; }

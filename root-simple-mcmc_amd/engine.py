@@ -231,6 +231,9 @@ class Engine:
         """nsteps x Step(save=false, metropolis) of every chain, one launch."""
         self._check(self._lib.smcmc_step(self._h, int(nsteps), int(metropolis)))
 
+    def snapshot(self): self._check(self._lib.smcmc_snapshot(self._h))
+    def rollback(self): self._check(self._lib.smcmc_rollback(self._h))
+
     def StepRecorded(self, nsteps, chain=0, metropolis=0):
         """nsteps x Step(false) in one launch with the per-step record of one chain (smcmc_step_recorded): a dict of
         arrays over the steps -- "accepted" / "proposed" [step][dim] and the scalars of smcmc_record_field."""

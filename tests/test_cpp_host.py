@@ -428,3 +428,38 @@ def test_step_column_with_fast_arithmetic_still_has_the_proposed_point(gpu, tmp_
     assert len({tuple(s) for s in steps}) == nsteps              # ... and a fresh one each time
     # a moved entry's step is the move (proposed - accepted-before, then accepted = proposed)
     np.testing.assert_allclose(steps[moved], (acc[1:] - acc[:-1])[moved], rtol=0, atol=1e-15)
+
+
+def _build_cpp(tmp_path, source, name):
+    exe = str(tmp_path / name)
+    cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-Werror", f"-I{os.path.join(ROOT, 'include')}",
+           os.path.join(ROOT, source), f"-L{LIBDIR}", "-lsmcmc_amd",
+           f"-Wl,-rpath,{LIBDIR}", "-Wl,-rpath,/opt/rocm/lib", "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return exe
+
+
+def test_step_loop_driver_compiles(smcmc, tmp_path):
+    _build_cpp(tmp_path, os.path.join("examples", "StepLoop_amd.C"), "step_loop.exe")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dim,cycles,steps", [(5, 3, 700), (50, 2, 450)])
+def test_run_ahead_step_is_the_same_chain(gpu, tmp_path, dim, cycles, steps):
+    """TSimpleMCMC::Step() running ahead of its caller (one launch of 16 ... 2048 recorded steps, served call by call;
+    setters / UpdateProposal() / SaveStep(true) rewind to a snapshot and replay) against Step() as one launch per call:
+    the SimpleMCMC.C schedule -- per-step SaveStep(false), the getters the driver prints, UpdateProposal() and the
+    per-cycle setters -- writes the same tree, entry for entry and bit for bit."""
+    exe = _build_cpp(tmp_path, os.path.join("examples", "StepLoop_amd.C"), "step_loop.exe")
+    outs = []
+    for ahead in (0, 1):
+        out = tmp_path / f"tree{ahead}.csv"
+        r = subprocess.run([exe, str(dim), str(cycles), str(steps), "1", str(ahead), str(out)], capture_output=True, text=True,
+                           timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert f"run_ahead {ahead}" in r.stdout
+        outs.append((open(out).read(), r.stdout.split("moved")[1].split("run_ahead")[0] + r.stdout.split("printed")[1]))
+    assert outs[0][1] == outs[1][1]                      # moved / entries / the printed getters
+    assert outs[0][0] == outs[1][0]                      # the trees, as text: every column of every entry
+    assert len(outs[0][0].splitlines()) == cycles * steps + 2

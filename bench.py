@@ -337,10 +337,10 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` as typed: this process becomes the launcher of N rank processes, one per GPU, and
-        # stays off the GPU itself (counting devices does not create a HIP context; nothing else here touches it)
+        # stays off the GPU itself (the GPUs are counted from the KFD topology, not through the HIP runtime)
         try:
             code, out = pkg.distributed.launch_local_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
-                                                           args.gpus, torch.cuda.device_count())
+                                                           args.gpus, pkg.distributed.visible_gpus())
         except RuntimeError as exc:
             raise SystemExit("bench.py --gpus %d: %s" % (args.gpus, exc))
         sys.stdout.write(out)

@@ -139,6 +139,7 @@ struct smcmc_engine {
     double* d_pc_tmpl = nullptr;   // what the host hands to every chain at Start / Restore / ResetProposal: cov packed, then ut
     int* d_pc_flag = nullptr;      // chains that stopped for the host's fallback ladder in the latest launch
     bool pc_frozen = false;        // SMCMC_P_COVARIANCE_FROZEN
+    bool pc_broken = false;        // a per-chain launch ended in an error with the chains part-way: Start / Restore again
     int pc_wave = -1;              // SMCMC_P_PERCHAIN_WAVE: -1 automatic, 0 / 1 one chain per lane / per wavefront
     smcmc::PerChainRecord pc_rec = {nullptr, 0, 0};   // the per-step record of the launch in progress (smcmc_step_recorded)
     double* d_pc_rec = nullptr;    // its device buffer
@@ -995,8 +996,15 @@ int launch(smcmc_engine* h, int nsteps, int metropolis, int stride, double* save
     if (per_chain(h)) {
         int st = pc_check_supported(h);
         if (st) return st;
+        if (h->pc_broken)
+            return fail(h, SMCMC_ERR_LOGIC, "an earlier launch of this per-chain ensemble ended in an error with its chains part-way "
+                                            "through (the reference's Step() would have thrown, TSimpleMCMC.H:1025-1028): Start or Restore it");
         st = pc_run(h, pc_params(h, p));
-        if (st) return st;
+        if (st) {
+            // the chains that ran have moved their own step counts and state; the ensemble's count has not: terminal
+            h->pc_broken = true;
+            return st;
+        }
         h->total_steps += (uint32_t)nsteps;
         h->has_forced = false;
         return SMCMC_OK;
@@ -1619,6 +1627,8 @@ int smcmc_start(smcmc_engine* h, const double* x0, int broadcast) {
     h->total_steps = 0;
     h->has_forced = false;
     h->started = true;
+    h->pc_broken = false;
+    h->snap_valid = false;
     return SMCMC_OK;
 }
 
@@ -2100,15 +2110,13 @@ int smcmc_read_chain_proposal(smcmc_engine* h, int chain, double* centre, double
     return SMCMC_OK;
 }
 
-// SMCMC_MODE_PER_CHAIN: a [rows] vector handed to every chain's column
+// SMCMC_MODE_PER_CHAIN: a [rows] vector handed to every chain's column, on the device (the vector goes up once; a host
+// image of the whole array would be 0.67 GB for a covariance at D = 50 x 65 536 chains)
 static int pc_broadcast_rows(smcmc_engine* h, double* dst, const double* values, int rows, bool tiled) {
-    const size_t NP = (size_t)h->npad;
-    std::vector<double> img((size_t)rows * NP, 0.0);
-    for (int r = 0; r < rows; ++r)
-        for (int c = 0; c < h->nchains; ++c)
-            img[tiled ? smcmc::pc_tile_index(r, (size_t)c, rows) : (size_t)r * NP + c] = values[r];
-    HIP_TRY(h, hipMemcpyAsync(dst, img.data(), img.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_pc_tmpl, values, (size_t)rows * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));   // pageable source
+    const hipError_t e = launch_perchain_broadcast_rows(dst, h->d_pc_tmpl, rows, h->nchains, (size_t)h->npad, tiled, h->stream);
+    if (e != hipSuccess) return fail(h, SMCMC_ERR_HIP, std::string("per-chain broadcast launch: ") + hipGetErrorString(e));
     return SMCMC_OK;
 }
 

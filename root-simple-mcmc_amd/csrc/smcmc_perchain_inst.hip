@@ -86,6 +86,22 @@ __global__ void perchain_broadcast_kernel(const PerChainBroadcast p) {
     li[SMCMC_LANE_UPDATE_COUNT * NP] = li[SMCMC_LANE_UPDATE_COUNT * NP] + 1;
 }
 
+// values[rows] into every chain's column of a [rows][npad] image (tiled: a wavefront-tiled image, pc_tile_index)
+__global__ void perchain_broadcast_rows_kernel(double* dst, const double* __restrict__ values, int rows, int nchains, size_t npad,
+                                               int tiled) {
+    const size_t chain = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (chain >= (size_t)nchains) return;
+    for (int r = 0; r < rows; ++r) dst[tiled ? pc_tile_index(r, chain, rows) : (size_t)r * npad + chain] = values[r];
+}
+
+hipError_t launch_perchain_broadcast_rows(double* dst, const double* values_device, int rows, int nchains, size_t npad, bool tiled,
+                                          hipStream_t s) {
+    if (!dst || !values_device || rows < 1 || nchains < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(perchain_broadcast_rows_kernel, dim3((nchains + 255) / 256), dim3(256), 0, s, dst, values_device, rows, nchains,
+                       npad, tiled ? 1 : 0);
+    return hipGetLastError();
+}
+
 hipError_t launch_perchain_broadcast(const PerChainBroadcast& p, hipStream_t s) {
     if (p.dim < 1 || p.dim > kPcMaxDim || p.nchains < 1 || p.nchains > p.npad) return hipErrorInvalidValue;
     hipLaunchKernelGGL(perchain_broadcast_kernel, dim3((p.nchains + 255) / 256), dim3(256), 0, s, p);

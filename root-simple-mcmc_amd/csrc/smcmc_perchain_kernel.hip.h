@@ -709,5 +709,7 @@ inline size_t perchain_lds_bytes(int dim) {
 
 hipError_t launch_perchain(const PerChainParams& p, int like, hipStream_t stream);
 hipError_t launch_perchain_broadcast(const PerChainBroadcast& p, hipStream_t stream);
+hipError_t launch_perchain_broadcast_rows(double* dst, const double* values_device, int rows, int nchains, size_t npad, bool tiled,
+                                          hipStream_t stream);
 
 }  // namespace smcmc

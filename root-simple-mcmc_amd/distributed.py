@@ -125,6 +125,31 @@ def free_port(addr="127.0.0.1"):
         return s.getsockname()[1]
 
 
+def visible_gpus():
+    """GPUs of this node without touching the HIP runtime (the launcher parent must stay off the GPU): the visibility
+    variables if they are set, else the KFD topology (nodes with SIMDs are GPUs), else torch's count (which, on this
+    image, does not initialise the runtime either)."""
+    import os
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([x for x in v.split(",") if x.strip() != ""])
+    nodes = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        n = 0
+        for d in os.listdir(nodes):
+            with open(os.path.join(nodes, d, "properties")) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+        if n > 0:
+            return n
+    except (OSError, ValueError):
+        pass
+    import torch
+    return torch.cuda.device_count()
+
+
 def launch_local_ranks(argv, nranks, visible_devices, timeout=None):
     """Start `nranks` fresh processes of `argv` (one per GPU of this node), rank r on device r, and return
     (exit code, rank 0's stdout).  The caller must not have touched the GPU: the children are plain child processes of
@@ -135,18 +160,42 @@ def launch_local_ranks(argv, nranks, visible_devices, timeout=None):
     if visible_devices < nranks:
         raise RuntimeError("%d ranks asked for, %d GPU(s) visible on this node: one rank per GPU" % (nranks, visible_devices))
     envs = rank_environments(nranks, free_port(), os.environ)
+    import threading
+    import time
     procs = []
     for r, env in enumerate(envs):
         procs.append(subprocess.Popen(argv, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate(timeout=timeout)
-    code = procs[0].returncode
-    for p in procs[1:]:
-        try:
-            p.wait(timeout=60 if code == 0 else 5)
-        except subprocess.TimeoutExpired:
-            p.kill()          # exactly the process this function started
-            p.wait()
-        code = code or p.returncode
+    # rank 0's line is read on the side, while EVERY child is watched: a rank that dies during rendezvous or RCCL
+    # initialisation would leave the others waiting in a collective for ever
+    out_box = []
+    reader = threading.Thread(target=lambda: out_box.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    deadline = None if timeout is None else time.monotonic() + timeout
+    code = 0
+    while True:
+        states = [p.poll() for p in procs]
+        bad = [c for c in states if c not in (None, 0)]
+        if bad:
+            code = bad[0]
+            break
+        if all(c == 0 for c in states):
+            break
+        if deadline is not None and time.monotonic() > deadline:
+            code = 124
+            break
+        time.sleep(0.05)
+    if code != 0:
+        for p in procs:          # exactly the processes this function started
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=5)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+    reader.join(timeout=5)
+    out = out_box[0] if out_box else b""
     return code, out.decode() if out else ""
 
 

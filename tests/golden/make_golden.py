@@ -8,7 +8,8 @@ reproduces them, the GPU suite checks the HIP path against them without the
 oracle in the loop.  Run from the repo root:  python tests/golden/make_golden.py   (everything)
 or  python tests/golden/make_golden.py --round2 / --round3   (only the fixtures of that round that are not there yet);
 --all rewrites every fixture (needed whenever include/smcmc_detmath.h changes the draws: round 3 did, Philox4x32-7 and the
-table-driven normal transform).
+table-driven normal transform).  Since round 3 the fixtures are FROZEN (MANIFEST.json): the script refuses to run
+without --i-am-changing-the-arithmetic.
 """
 import os
 import sys
@@ -245,4 +246,11 @@ def main():
 
 
 if __name__ == "__main__":
+    # The fixtures are frozen (MANIFEST.json, tests/test_golden.py::test_the_fixtures_are_the_frozen_ones): a kernel
+    # change has to reproduce them.  Regenerating is a decision, not a build step.
+    if "--i-am-changing-the-arithmetic" not in sys.argv:
+        raise SystemExit("tests/golden/*.npz are frozen since round 3 (MANIFEST.json).  To regenerate them because the engine's "
+                         "DEFINITION changed (draws, summation order), pass --i-am-changing-the-arithmetic, update MANIFEST.json "
+                         "and say so in DESIGN.md.")
+    sys.argv.remove("--i-am-changing-the-arithmetic")
     main()

@@ -365,3 +365,18 @@ def test_hip_reproduces_perchain_golden(gpu, name):
         centre, cov, dec = e.chain_proposal(ch)
         assert np.array_equal(centre, g["centre"][ch]) and np.array_equal(cov, g["covariance"][ch])
         assert np.array_equal(dec, g["decomposition"][ch])
+
+
+def test_the_fixtures_are_the_frozen_ones():
+    """tests/golden/*.npz are FROZEN: tests/golden/MANIFEST.json holds the hash of every fixture as of round 3, and a
+    round that changes a kernel has to reproduce these files, not regenerate them (round 4 rebuilt the large-dimension
+    moment fold and the per-chain mode against them).  A fixture may only change together with the manifest and a line
+    in DESIGN.md saying which arithmetic moved and why."""
+    import hashlib
+    import json
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    man = json.load(open(os.path.join(here, "MANIFEST.json")))["sha256"]
+    found = sorted(f for f in os.listdir(here) if f.endswith(".npz"))
+    assert found == sorted(man), "fixtures added or removed without the manifest"
+    for name in found:
+        assert hashlib.sha256(open(os.path.join(here, name), "rb").read()).hexdigest() == man[name], name

@@ -285,3 +285,33 @@ def test_restore_restatement(oracle):
     assert c.scalars["accepted_logl"] == near["log_likelihood"]
     d = oracle.Chain(dim, chain_id=3); d.start(np.zeros(dim)); d.restore(far)
     assert d.scalars["accepted_logl"] == st["log_likelihood"]
+
+
+def test_hmc_makes_leapfrog_plus_one_gradient_calls_per_step(oracle):
+    """SURVEY.md section 8(c), probed on the reference itself: TSimpleHMC at D = 100 with SetLeapFrog(20) makes exactly
+    21 gradient calls per Step() (TSimpleHMC.H:582-651: one to start the trajectory, one per leapfrog step)."""
+    dim = 100
+    h = oracle.Hmc(dim, kind=oracle.LIKE_ISO)
+    h.start(np.full(dim, 0.5))
+    h.set_mean_epsilon(-0.01)
+    h.set_leapfrog(20)
+    g0 = h.scalars["gradient_count"]
+    for k in range(1, 8):
+        h.step()
+        assert h.scalars["gradient_count"] - g0 == 21 * k
+
+
+@pytest.mark.parametrize("dim,expected,tol", [(5, 0.2325, 0.006), (50, 0.230, 0.006)])
+def test_acceptance_settles_where_the_reference_settles(oracle, dim, expected, tol):
+    """the reference (its own headers, ROOT's generator) ends 10^6 adaptive steps of the
+    iso-Gaussian at an acceptance of 0.2325 for D = 5 and 0.230 for D = 50.  The restatement on its own draws: the
+    fraction of accepted steps over the second half of 10^6 steps (Monte-Carlo error ~0.001 with the autocorrelation of
+    the accept flags; the step-size feedback of :1745-1776 holds it a little under the 0.234 target, as in the reference)."""
+    c = oracle.Chain(dim)
+    assert c.start(np.zeros(dim))
+    c.run_quiet(500000)
+    a0 = c.scalars["successes"]
+    c.run_quiet(500000)
+    rate = (c.scalars["successes"] - a0) / 500000.0
+    assert abs(rate - expected) < tol, rate
+    assert abs(c.scalars["acceptance"] - expected) < 0.03       # fAcceptance itself: a window of ~1000 steps

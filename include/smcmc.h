@@ -227,7 +227,9 @@ int smcmc_step(smcmc_engine* h, int nsteps, int metropolis);
  * >= dim are zero), save_logl[slot][nchains_padded]; slots = nsteps / stride. */
 /* nsteps x Step(false, metropolis) in one launch with a per-step record of one chain on the host: after every step
  * what TSimpleMCMC::Step() leaves in its members and SaveStep() reads -- records[step * smcmc_record_stride()]:
- * [0, dim) fAccepted, [dim, 2 dim) fProposed, then the scalars of smcmc_record_field.  SMCMC_MODE_PER_CHAIN with the
+ * [0, dim) fAccepted, [dim, 2 dim) fProposed, [2 dim, 3 dim) the diagonal of the chain's covariance (GetCovarianceTrace,
+ * TSimpleMCMC.H:961-967, is its sum in index order: the reader adds it up; SMCMC_REC_COVARIANCE_TRACE itself is 0), then
+ * the scalars of smcmc_record_field.  SMCMC_MODE_PER_CHAIN with the
  * one-chain-per-wavefront kernel (SMCMC_P_PERCHAIN_WAVE); SMCMC_ERR_UNSUPPORTED otherwise.  include/TSimpleMCMC_amd.H
  * runs Step() ahead with it (TSimpleMCMC.H:370-496 one call at a time is one launch and three read-backs per step). */
 typedef enum {
@@ -244,7 +246,7 @@ typedef enum {
  * settings changed in between (smcmc_set_param ...) are not part of the snapshot. */
 int smcmc_snapshot(smcmc_engine* h);
 int smcmc_rollback(smcmc_engine* h);
-int smcmc_record_stride(const smcmc_engine* h);      /* 2 dim + SMCMC_REC_COUNT_ */
+int smcmc_record_stride(const smcmc_engine* h);      /* 3 dim + SMCMC_REC_COUNT_ */
 int smcmc_step_recorded(smcmc_engine* h, int nsteps, int metropolis, int chain, double* records);
 int smcmc_step_save(smcmc_engine* h, int nsteps, int metropolis, int stride,
                     double* save_x_device, double* save_logl_device);

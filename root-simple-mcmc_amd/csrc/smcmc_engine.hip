@@ -1757,7 +1757,7 @@ int smcmc_rollback(smcmc_engine* h) {
     return SMCMC_OK;
 }
 
-int smcmc_record_stride(const smcmc_engine* h) { return h ? 2 * h->dim + smcmc::kPcRecScalars : 0; }
+int smcmc_record_stride(const smcmc_engine* h) { return h ? 3 * h->dim + smcmc::kPcRecScalars : 0; }
 
 int smcmc_step_recorded(smcmc_engine* h, int nsteps, int metropolis, int chain, double* records) {
     if (!h || !records) return SMCMC_ERR_INVALID;

@@ -34,8 +34,9 @@
 
 namespace smcmc {
 
-// Per-step record of one chain: rec[(step - step0 - 1) * stride + ...]: [0, D) fAccepted, [D, 2 D) fProposed, then the
-// scalars below.
+// Per-step record of one chain: rec[(step - step0 - 1) * stride + ...]: [0, D) fAccepted, [D, 2 D) fProposed, [2 D, 3 D) the
+// diagonal of the covariance (GetCovarianceTrace is its sum in index order: the reader adds it up when somebody asks),
+// then the scalars below.
 enum {
     kPcRecLogl = 0, kPcRecLoglProposed, kPcRecStepRms, kPcRecLastAccept, kPcRecTrials, kPcRecSuccesses, kPcRecNextUpdate,
     kPcRecAcceptance, kPcRecAcceptanceTrials, kPcRecSigma, kPcRecCenterTrials, kPcRecCovarianceTrials, kPcRecTrace,
@@ -46,7 +47,7 @@ static_assert(kPcRecScalars == SMCMC_REC_COUNT_ && kPcRecTrace == SMCMC_REC_COVA
 struct PerChainRecord {
     double* rec;     // nullptr: no record
     int chain;
-    int stride;      // doubles per step: >= 2 dim + kPcRecScalars
+    int stride;      // doubles per step: >= 3 dim + kPcRecScalars
 };
 
 constexpr int kPwBatch = 8;          // LDS values read ahead of the additions of an ordered sum
@@ -505,14 +506,17 @@ __global__ void __launch_bounds__(kWave) perchain_wave_kernel(const PerChainPara
                 if (lane == 0) p.save_logl[slot * NP + chain] = logl;
             }
             if (rec.rec != nullptr && chain == rec.chain) {
-                const double trace = trace_now();
                 double* r = rec.rec + (size_t)(tstep - p.step0 - 1u) * rec.stride;
                 if (mine) {
                     r[lane] = xi;
                     r[D + lane] = xpi;
                 }
+#pragma unroll
+                for (int q = 0; q < NE; ++q)
+                    if ((ij[q] >> 8) == (ij[q] & 255u) && lane + kWave * q < npk) r[2 * D + (ij[q] & 255u)] = cov[q];
+                const double trace = 0.0;     // (the reader sums the diagonal)
                 if (lane == 0) {
-                    double* s = r + 2 * D;
+                    double* s = r + 3 * D;
                     s[kPcRecLogl] = logl; s[kPcRecLoglProposed] = logl_prop; s[kPcRecStepRms] = step_rms;
                     s[kPcRecLastAccept] = last_accept; s[kPcRecTrials] = trials; s[kPcRecSuccesses] = succ;
                     s[kPcRecNextUpdate] = next_update; s[kPcRecAcceptance] = acc_rate; s[kPcRecAcceptanceTrials] = acc_trials;

@@ -27,7 +27,7 @@ hipError_t launch_perchain_wave(const PerChainParams& p, const PerChainRecord& r
     if (!p.x || !p.proposed || !p.last_point || !p.centre || !p.cov || !p.ut || !p.lane_f64 || !p.lane_i32 || !p.flag_count)
         return hipErrorInvalidValue;
     if (p.save_x && p.save_stride < 1) return hipErrorInvalidValue;
-    if (rec.rec && (rec.chain < 0 || rec.chain >= p.nchains || rec.stride < 2 * p.dim + kPcRecScalars)) return hipErrorInvalidValue;
+    if (rec.rec && (rec.chain < 0 || rec.chain >= p.nchains || rec.stride < 3 * p.dim + kPcRecScalars)) return hipErrorInvalidValue;
     switch (like) {
         case SMCMC_LIKE_ISO_GAUSS: return go_wave_like<SMCMC_LIKE_ISO_GAUSS>(p, rec, s);
         case SMCMC_LIKE_QUADFORM: return go_wave_like<SMCMC_LIKE_QUADFORM>(p, rec, s);

@@ -212,7 +212,6 @@ __global__ void __launch_bounds__(256) pooled_adjust_lanes_kernel(double* lane_f
 constexpr int kSmallDim = 64;
 __global__ void __launch_bounds__(512) pooled_small_update_kernel(const PooledUpdateParams p, const PooledPublishParams q) {
     __shared__ double R[kSmallDim][kSmallDim + 1];
-    __shared__ double s_piv;
     __shared__ int s_state;    // kPooledOk ...
     const int D = p.D;
     const int tid = threadIdx.x;
@@ -279,30 +278,47 @@ __global__ void __launch_bounds__(512) pooled_small_update_kernel(const PooledUp
         if (tid == 0) p.scal[kPsStatus] = s_state;
         return;
     }
-    // ---- SharedProposal::cholesky: row c of U from the rows above it, one thread per column ----
-    const int jj = tid;
-    for (int c = 0; c < D; ++c) {
-        double v = 0.0;
-        if (jj >= c && jj < D) {
-            v = R[c][jj];
-            for (int rr = 0; rr < c; ++rr) v -= R[rr][jj] * R[rr][c];
-            if (jj == c) {
-                if (!(v > 0.0) || !__builtin_isfinite(v)) {
-                    s_state = kPooledCholeskyFailed;
-                } else {
-                    const double piv = __builtin_sqrt(v);
-                    R[c][c] = piv;
-                    s_piv = piv;
+    // ---- SharedProposal::cholesky: row c of U from the rows above it, one lane per column ----
+    // ONE wavefront does it (D <= 64 columns): no workgroup barrier between the rows, only the order of its own LDS
+    // operations, and all the operands of a row's subtractions are read ahead of the chain of subtractions (a row of
+    // 512 threads and two barriers cost 46 us per window at D = 50, 1.1 % of the headline: the dependent
+    // read-multiply-subtract of its inner loop at one LDS latency per term).  Same subtractions in the same order:
+    // v -= U(rr, j) U(rr, c), rr ascending, un-fused.
+    if (tid < 64) {
+        const int jj = tid;
+        int state = kPooledOk;
+        for (int c = 0; c < D && state == kPooledOk; ++c) {
+            double v = R[c][jj < D ? jj : 0];
+            for (int r0 = 0; r0 < c; r0 += 16) {
+                double a[16], bq[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int rr = (r0 + u < c) ? r0 + u : 0;
+                    a[u] = R[rr][jj < D ? jj : 0];
+                    bq[u] = R[rr][c];
                 }
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+                    if (r0 + u < c) v -= a[u] * bq[u];
             }
+            const double piv = __shfl(v, c);
+            if (!(piv > 0.0) || !__builtin_isfinite(piv)) {
+                state = kPooledCholeskyFailed;
+            } else {
+                const double root = __builtin_sqrt(piv);
+                if (jj == c) R[c][c] = root;
+                else if (jj > c && jj < D) R[c][jj] = v / root;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         }
-        __syncthreads();
-        if (s_state != kPooledOk) {
-            if (tid == 0) p.scal[kPsStatus] = s_state;
-            return;
-        }
-        if (jj > c && jj < D) R[c][jj] = v / s_piv;
-        __syncthreads();
+        if (tid == 0) s_state = state;
+    }
+    __syncthreads();
+    if (s_state != kPooledOk) {
+        if (tid == 0) p.scal[kPsStatus] = s_state;
+        return;
     }
     // ---- the decomposition (zeros below the diagonal) and the step kernels' padded copy ----
     for (int k = tid; k < D * D; k += 512) {

@@ -240,9 +240,12 @@ class Engine:
         stride = self._lib.smcmc_record_stride(self._h)
         rec = np.zeros((int(nsteps), stride))
         self._check(self._lib.smcmc_step_recorded(self._h, int(nsteps), int(metropolis), int(chain), _ptr(rec)))
-        out = {"accepted": rec[:, :self.dim].copy(), "proposed": rec[:, self.dim:2 * self.dim].copy()}
+        out = {"accepted": rec[:, :self.dim].copy(), "proposed": rec[:, self.dim:2 * self.dim].copy(),
+               "covariance_diagonal": rec[:, 2 * self.dim:3 * self.dim].copy()}
         for k, name in enumerate(_capi.RECORD_FIELDS):
-            out[name] = rec[:, 2 * self.dim + k].copy()
+            out[name] = rec[:, 3 * self.dim + k].copy()
+        # GetCovarianceTrace (TSimpleMCMC.H:961-967): the diagonal added up in index order
+        out["covariance_trace"] = np.add.accumulate(out["covariance_diagonal"], axis=1)[:, -1]
         return out
 
     def StepSave(self, nsteps, save_x_ptr, save_logl_ptr, stride=1, metropolis=0):

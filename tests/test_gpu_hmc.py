@@ -397,8 +397,8 @@ def test_hmc_backend_exchange_and_the_pending_guard(gpu):
     the apply of the first is refused (SMCMC_ERR_LOGIC) instead of silently dropping a window's moments."""
     import torch
     from root_simple_mcmc_amd import distributed as D
-    dim, n, window = 24, 2048, 3
-    whole = gpu.HmcEngine(dim, n, seed=9)
+    dim, n, window = 24, 4096, 3                    # halves of 2 048 chains: whole chunks of 32 moment groups, so the shards'
+    whole = gpu.HmcEngine(dim, n, seed=9)           # sums add up in the single engine's order
     whole.SetSyncInterval(window)
     halves = [gpu.HmcEngine(dim, n // 2, seed=9, chain_offset=k * (n // 2)) for k in range(2)]
     x0 = np.full(dim, 0.3)

@@ -10,5 +10,5 @@ for dim in (50, 5):
     e.Step(100)
     n = 512
     rec = e.StepRecorded(n)
-    t = rec["accepted"][0][:8] if dim >= 8 else np.concatenate([rec["accepted"][0], rec["proposed"][0]])[:8]
+    t = np.concatenate([rec["accepted"][0], rec["proposed"][0]])[:8]
     print("D =", dim, "cycles per step:", " | ".join("%s %.0f" % (nm, v / n) for nm, v in zip(names, t)), "| total %.0f" % (t.sum() / n))

@@ -221,11 +221,21 @@ __global__ void __launch_bounds__(kWave) perchain_wave_kernel(const PerChainPara
     double xi = p.x[own], ci = p.centre[own], lasti = p.last_point[own], xpi = p.proposed[own];
     double cov[NE];
     uint32_t ij[NE];                     // (row << 8 | column) of element k = lane + 64 r
+    // Which of this lane's registers hold an element at all, and which a diagonal one: as BIT masks, tested where they
+    // are used.  (As conditions on `lane + 64 r < npk` they are loop-invariant lane masks: the compiler keeps all 2 NE of
+    // them in SGPR pairs across the step loop, runs out of SGPRs and moves them through VGPR lanes at every use --
+    // a thousand v_readlane / v_writelane in the first build.)  A register past the end computes on two entries of LDS
+    // nobody writes; it is never stored.
+    uint32_t valid_bits = 0, diag_bits = 0;
 #pragma unroll
     for (int r = 0; r < NE; ++r) {
         const int k = lane + kWave * r;
-        int i = 0, j = 0;
-        if (k < npk) pc_unpack(k, i, j);
+        int i = 62, j = 63;
+        if (k < npk) {
+            pc_unpack(k, i, j);
+            valid_bits |= 1u << r;
+            if (i == j) diag_bits |= 1u << r;
+        }
         ij[r] = (uint32_t)(i << 8 | j);
         cov[r] = (k < npk) ? p.cov[pc_tile_index(k, (size_t)chain, npk)] : 0.0;
     }
@@ -251,9 +261,11 @@ __global__ void __launch_bounds__(kWave) perchain_wave_kernel(const PerChainPara
         __syncthreads();
         sv[lane] = 0.0;
         __syncthreads();
+        uint32_t db = diag_bits;
+        asm volatile("" : "+v"(db));     // (tested here, not hoisted out of the step loop as NE lane masks)
 #pragma unroll
         for (int r = 0; r < NE; ++r)
-            if ((ij[r] >> 8) == (ij[r] & 255u) && lane + kWave * r < npk) sv[ij[r] & 255u] = cov[r];
+            if ((db >> r) & 1u) sv[ij[r] & 255u] = cov[r];
         __syncthreads();
         return pw_sum_lds<DMAX>(sv, D);
     };
@@ -283,9 +295,13 @@ __global__ void __launch_bounds__(kWave) perchain_wave_kernel(const PerChainPara
         }
         // the decomposition in place in LDS: A(c, j) = cov(j, c) sits where U(c, j) will (the same packed index)
         __syncthreads();
+        {
+            uint32_t vb = valid_bits;
+            asm volatile("" : "+v"(vb));
 #pragma unroll
-        for (int r = 0; r < NE; ++r)
-            if (lane + kWave * r < npk) ul[lane + kWave * r] = cov[r];
+            for (int r = 0; r < NE; ++r)
+                if ((vb >> r) & 1u) ul[lane + kWave * r] = cov[r];
+        }
         __syncthreads();
         bool ok = true;
         // SharedProposal::cholesky (smcmc_proposal.hpp): row c of U from the rows above it
@@ -386,7 +402,7 @@ __global__ void __launch_bounds__(kWave) perchain_wave_kernel(const PerChainPara
                         t *= tv;
                         t += rr;
                         t /= tv1;
-                        cov[r] = (lane + kWave * r < npk) ? t : 0.0;
+                        cov[r] = t;
                     }
                     cov_trials = dmin(p.cov_window, cov_trials + 1.0);
                 }
@@ -511,9 +527,13 @@ __global__ void __launch_bounds__(kWave) perchain_wave_kernel(const PerChainPara
                     r[lane] = xi;
                     r[D + lane] = xpi;
                 }
+                {
+                    uint32_t db = diag_bits;
+                    asm volatile("" : "+v"(db));
 #pragma unroll
-                for (int q = 0; q < NE; ++q)
-                    if ((ij[q] >> 8) == (ij[q] & 255u) && lane + kWave * q < npk) r[2 * D + (ij[q] & 255u)] = cov[q];
+                    for (int q = 0; q < NE; ++q)
+                        if ((db >> q) & 1u) r[2 * D + (ij[q] & 255u)] = cov[q];
+                }
                 const double trace = 0.0;     // (the reader sums the diagonal)
                 if (lane == 0) {
                     double* s = r + 3 * D;

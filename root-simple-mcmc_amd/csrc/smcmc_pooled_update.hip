@@ -212,6 +212,7 @@ __global__ void __launch_bounds__(256) pooled_adjust_lanes_kernel(double* lane_f
 constexpr int kSmallDim = 64;
 __global__ void __launch_bounds__(512) pooled_small_update_kernel(const PooledUpdateParams p, const PooledPublishParams q) {
     __shared__ double R[kSmallDim][kSmallDim + 1];
+    __shared__ double s_piv;
     __shared__ int s_state;    // kPooledOk ...
     const int D = p.D;
     const int tid = threadIdx.x;
@@ -280,27 +281,26 @@ __global__ void __launch_bounds__(512) pooled_small_update_kernel(const PooledUp
     }
     // ---- SharedProposal::cholesky: row c of U from the rows above it, one lane per column ----
     // ONE wavefront does it (D <= 64 columns): no workgroup barrier between the rows, only the order of its own LDS
-    // operations, and all the operands of a row's subtractions are read ahead of the chain of subtractions (a row of
-    // 512 threads and two barriers cost 46 us per window at D = 50, 1.1 % of the headline: the dependent
-    // read-multiply-subtract of its inner loop at one LDS latency per term).  Same subtractions in the same order:
-    // v -= U(rr, j) U(rr, c), rr ascending, un-fused.
+    // operations (a wavefront's LDS instructions execute in issue order), and the operands of a row's subtractions are
+    // read sixteen ahead of the chain of subtractions.  Same subtractions in the same order: v -= U(rr, j) U(rr, c), rr
+    // ascending, un-fused.
     if (tid < 64) {
-        const int jj = tid;
+        const int jj = tid, jc = jj < D ? jj : 0;
         int state = kPooledOk;
         for (int c = 0; c < D && state == kPooledOk; ++c) {
-            double v = R[c][jj < D ? jj : 0];
-            for (int r0 = 0; r0 < c; r0 += 16) {
+            double v = R[c][jc];
+            int r0 = 0;
+            for (; r0 + 16 <= c; r0 += 16) {
                 double a[16], bq[16];
 #pragma unroll
                 for (int u = 0; u < 16; ++u) {
-                    const int rr = (r0 + u < c) ? r0 + u : 0;
-                    a[u] = R[rr][jj < D ? jj : 0];
-                    bq[u] = R[rr][c];
+                    a[u] = R[r0 + u][jc];
+                    bq[u] = R[r0 + u][c];
                 }
 #pragma unroll
-                for (int u = 0; u < 16; ++u)
-                    if (r0 + u < c) v -= a[u] * bq[u];
+                for (int u = 0; u < 16; ++u) v -= a[u] * bq[u];
             }
+            for (; r0 < c; ++r0) v -= R[r0][jc] * R[r0][c];
             const double piv = __shfl(v, c);
             if (!(piv > 0.0) || !__builtin_isfinite(piv)) {
                 state = kPooledCholeskyFailed;
@@ -309,9 +309,8 @@ __global__ void __launch_bounds__(512) pooled_small_update_kernel(const PooledUp
                 if (jj == c) R[c][c] = root;
                 else if (jj > c && jj < D) R[c][jj] = v / root;
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the row is in LDS before the next row reads it
             __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         }
         if (tid == 0) s_state = state;
     }

@@ -84,6 +84,9 @@ def perchain(src, dst):
     pf, pw = glob.glob(f"{src}/pc_fetch/*/*_counter_collection.csv"), glob.glob(f"{src}/pc_write/*/*_counter_collection.csv")
     if os.path.exists(f"{src}/perchain.json"):
         shutil.copy(f"{src}/perchain.json", f"{dst}_perchain.json")
+    for name in ("perchain_wave.json", "fold_bench.txt", "fold_prof.txt", "ordered_sum.txt"):
+        if os.path.exists(f"{src}/{name}"):
+            shutil.copy(f"{src}/{name}", f"{dst}_{name}")
     if not pf or not pw:
         return
     name = "perchain_step_kernel"

@@ -303,6 +303,84 @@ def cpp_step_loop(dim, cycles, steps, runahead, save=False):
                 "moved": int(words[words.index("moved") + 1])}
 
 
+def bench_c5(args, pkg, torch, dist, rank, world, local, stream, leapfrog=20):
+    """BASELINE config 5 over N GPUs: every rank runs its shard of TSimpleHMC chains (quadratic form with variances
+    0.25 .. 4, a target the reference's own tuning handles; start at 1, SimpleHMC.C:45; SetLeapFrog(20); every chain
+    tuning its own step length from SetMeanEpsilon(0.05)), the covariance fold runs every trajectory, and every `window`
+    trajectories the moments are all-reduced and UpdateCovariance / UpdateErrorMatrix run on every rank on the same
+    bits (distributed.run_windows over HmcBackend).  A "step" of the contract is one such window."""
+    dim, chains = args.dim, args.chains
+    h = pkg.HmcEngine(dim, chains, likelihood=pkg.LIKE_QUADFORM, likelihood_params=np.diag(1.0 / np.linspace(0.25, 4.0, dim)),
+                      seed=20240607, chain_offset=rank * chains, device=local, exact=not args.fast, stream=stream.cuda_stream)
+    h.Start(np.ones(dim))
+    h.SetMeanEpsilon(0.05)
+    h.SetLeapFrog(leapfrog)
+    backend = pkg.distributed.HmcBackend(h, time_steps=True, stream=stream)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    pkg.distributed.run_windows(backend, args.warmup, args.window)
+    backend.events.clear(); backend.comm_events.clear()
+    acc0, tr0 = h.lane("naccept").astype(np.float64).sum(), h.lane("trials").astype(np.float64).sum()
+    gc.collect(); gc.disable()
+    fence()
+    t0 = time.perf_counter()
+    pkg.distributed.run_windows(backend, args.steps, args.window)
+    fence()
+    dt = time.perf_counter() - t0
+    gc.enable()
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    acc1, tr1 = h.lane("naccept").astype(np.float64).sum(), h.lane("trials").astype(np.float64).sum()
+    kms = float(np.mean([a.elapsed_time(b) for a, b in backend.events]))
+    kernel_ms_per_rank = None
+    if world > 1:
+        mine = torch.zeros(world, dtype=torch.float64, device="cuda")
+        mine[rank] = kms
+        dist.all_reduce(mine, op=dist.ReduceOp.SUM)
+        kernel_ms_per_rank = [float(v) for v in mine.cpu()]
+    rate = float(chains) * world * args.window * args.steps / dt
+    flops = (leapfrog + 1) * 2 * dim * dim + 3 * dim * dim + dim * dim      # SURVEY.md 8(d), per trajectory
+    per_launch = float(chains) * args.window
+    out = {
+        "metric": "trajectories/s, TSimpleHMC D=500, 8 192 chains per GPU x 20 leapfrog steps (BASELINE config 5, sharded)",
+        "value": rate, "unit": "trajectories/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "rccl_ranks": dist.get_world_size() if world > 1 else 1,
+        "ms_allreduce": (float(np.mean([a.elapsed_time(b) for a, b in backend.comm_events])) if backend.comm_events else None),
+        "kernel_ms_per_rank": kernel_ms_per_rank,
+        "comm": "none (one rank)" if world == 1 else "torch.distributed nccl (= RCCL)",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic", "rng": "philox4x32-7",
+        "config": {"workload": "BASELINE config 5: TSimpleHMC, quadratic form with variances 0.25..4 and its analytic gradient, "
+                               "D=%d, %d chains/GPU x %d leapfrog steps, self-tuned step length from SetMeanEpsilon(0.05), "
+                               "pooled covariance retuning every %d trajectories%s" %
+                               (dim, chains, leapfrog, args.window,
+                                " (%d chains over %d GPUs, one all-reduce of the moments per window)" % (chains * world, world)
+                                if world > 1 else ""),
+                   "baseline_config": 5, "dim": dim, "chains_per_gpu": chains, "leapfrog": leapfrog, "window": args.window,
+                   "arithmetic": "fused (matrix pipe)" if args.fast else "reference-order", "seed": 20240607},
+        "accept_rate": float((acc1 - acc0) / max(tr1 - tr0, 1.0)),
+        "mean_abs_epsilon": float(np.abs(h.lane("mean_epsilon")).mean()),
+        "covariance_updates": h.tuning["updates"],
+        "roofline": {"bound": "mfma", "achieved": per_launch * flops / (kms * 1e-3) / 1e12,
+                     "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": per_launch * flops / (kms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                     "traffic": None,
+                     "note": "FP64 vector/matrix peak; flops per trajectory = (L + 1) 2 D^2 + 4 D^2 (SURVEY.md 8(d)); kernel time = "
+                             "HIP events around the window's launches on the engine's stream"},
+    }
+    if rank == 0:
+        print(json.dumps(out))
+    h.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -318,10 +396,13 @@ def main():
     ap.add_argument("--dim", type=int, default=DIM, help="diagnostic: other dimension (not the headline)")
     ap.add_argument("--header-tdummy", action="store_true",
                     help="diagnostic: the headline loop on the other C2 likelihood (header-form TDummyLogLikelihood)")
-    ap.add_argument("--config", choices=("c2", "c4"), default="c2",
+    ap.add_argument("--config", choices=("c2", "c4", "c5"), default="c2",
                     help="c2 (default, the headline): BASELINE config 2, D=50, 65 536 chains per GPU.  c4: BASELINE config 4, "
                          "D=500, 32 768 chains per GPU (262 144 over 8), all-reduce of the pooled covariance every 256 steps; "
-                         "README-form likelihood, or the header form with --header-tdummy")
+                         "README-form likelihood, or the header form with --header-tdummy.  c5: BASELINE config 5 sharded, "
+                         "TSimpleHMC D=500, 8 192 chains per GPU x 20 leapfrog steps, the chains tuning their own step length, "
+                         "the covariance-driven retuning pooled over all ranks every --window trajectories "
+                         "(distributed.HmcBackend through run_windows; default window 8)")
     ap.add_argument("--native-comm", action="store_true",
                     help="N > 1: the moment all-reduce through the library's own RCCL communicator (smcmc_comm_init / "
                          "smcmc_allreduce_moments, the C / C++ callers' path) instead of torch.distributed")
@@ -330,6 +411,10 @@ def main():
         # the defaults of config 4 where the command line left the config-2 ones
         if args.dim == DIM: args.dim = 500
         if args.chains == CHAINS_PER_GPU: args.chains = 32768
+    if args.config == "c5":
+        if args.dim == DIM: args.dim = 500
+        if args.chains == CHAINS_PER_GPU: args.chains = 8192
+        if args.window == WINDOW: args.window = 8
 
     import torch
     from smcmc_amd_loader import load_package
@@ -365,6 +450,8 @@ def main():
 
     stream = torch.cuda.current_stream()
     dim = args.dim
+    if args.config == "c5":
+        return bench_c5(args, pkg, torch, dist, rank, world, local, stream)
     like_name, like, like_params = "iso", pkg.LIKE_ISO_GAUSS, None
     if args.header_tdummy:
         like_name, like, like_params = "quadform", pkg.LIKE_QUADFORM, tdummy_error(dim)

@@ -1,7 +1,7 @@
 // The unchanged caller's loop (SimpleMCMC.C:176-243): one chain of sMCMC::TSimpleMCMC<TIsoGaussLogLikelihood> adapting
 // as the reference does, `for (...) mcmc.Step(save)` one call at a time, the getters SimpleMCMC.C:209-219 prints read
 // every `verbosity` steps, UpdateProposal() + the per-cycle setters (SimpleMCMC.C:245-256) at the end of every cycle.
-// argv: dim cycles steps save(0|1) runahead(0|1) [out.csv]
+// argv: dim cycles steps save(0|1) runahead(0|1) [out.csv [chains]]   (chains > 1: an ensemble, each chain adapting alone)
 // Prints "steps_per_s <rate>" for the timed loop, and -- for the parity test -- with out.csv the tree (every entry's
 // LogLikelihood / Accepted / Adaptive* columns) so that the run-ahead Step() can be diffed against Step() one launch
 // at a time: they are the same chain.
@@ -18,6 +18,7 @@ int main(int argc, char** argv) {
         sMCMC::TreeType tree("SimpleMCMC", "");
         sMCMC::TSimpleMCMC<sMCMC::TIsoGaussLogLikelihood> mcmc(&tree, true);
         mcmc.SetRunAhead(ahead);
+        if (argc > 7) { mcmc.SetChains(std::atoi(argv[7])); mcmc.GetProposeStep().SetPerChainAdaptation(true); }
         mcmc.GetProposeStep().SetDim(dim);
         sMCMC::Vector p((std::size_t)dim, 0.0);
         if (!mcmc.Start(p, false)) return 1;

@@ -244,6 +244,13 @@ __global__ void __launch_bounds__(W * kWave) panel_step_kernel(const PanelParams
     constexpr int ngather = (CW + kGatherJl - 1) / kGatherJl;
 
     double xp[CW];
+    // PANEL_PROFILE (tools/micro/build_panelprof.sh): cycles per section, printed by workgroup 0 -- never a product build
+#ifdef PANEL_PROFILE
+    unsigned long long tsec[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+#define PN_MARK(k) { const unsigned long long tn_ = __builtin_readcyclecounter(); tsec[k] += tn_ - tlast; tlast = tn_; }
+#else
+#define PN_MARK(k)
+#endif
     for (int s = 0; s < p.nsteps; ++s) {
         const uint64_t step = (uint64_t)(p.step0 + (uint32_t)s + 1u);
         // W = 4: the row pitch is opaque per step, otherwise the 3 x 64 column addresses are hoisted out of the
@@ -304,9 +311,11 @@ __global__ void __launch_bounds__(W * kWave) panel_step_kernel(const PanelParams
             verdict_logl[lane] = smcmc_u01(smcmc_select_word(blk, aw & 3u));
         }
         const int ncols = (D - w + W - 1) / W;   // local columns of this wavefront that exist (j = jl * W + w < D)
+        PN_MARK(0)
         for (int pn = 0; pn < (no_update ? 0 : npanels); ++pn) {
             const int i0 = pn * kPanelRows;
             __syncthreads();                       // the previous panel has been consumed
+            PN_MARK(1)
             // normals of rows i0 .. i0+KP-1: Philox block b covers rows 4b..4b+3
             for (int bb = w; bb < kPanelRows / 4; bb += W) {
                 const int b = i0 / 4 + bb;
@@ -321,6 +330,7 @@ __global__ void __launch_bounds__(W * kWave) panel_step_kernel(const PanelParams
                 }
             }
             const int i1 = (i0 + kPanelRows < D) ? i0 + kPanelRows : D;
+            PN_MARK(2)
             // this wavefront's slice of the panel, rows i0..i1-1 x CW columns, is contiguous in
             // Uperm: copy it into the wavefront's LDS area with 16-byte pieces
             {
@@ -340,9 +350,14 @@ __global__ void __launch_bounds__(W * kWave) panel_step_kernel(const PanelParams
                         if (k0 + u * kWave < npieces) dst[k0 + u * kWave] = t[u];
                 }
             }
+            PN_MARK(3)
             __syncthreads();
+            PN_MARK(1)
             lds_cptr_f64 up = (lds_cptr_f64)(ulds + w * (kPanelRows * CW));
             asm volatile("" : "+v"(up));   // LDS addresses live in vector registers
+            // (tools/micro/panelprof.py: this loop is 187 000 of the 292 000 cycles of a config-3 step, ~400 cycles per
+            // 16-column piece against 128 of arithmetic -- the four wavefronts' broadcast reads queue at the CU's one LDS
+            // pipe.  Products first / the next piece's reads issued behind them / additions last was measured: 207 000.)
             for (int i = i0; i < i1; ++i) {
                 const double sr = sigma * rbuf[(i - i0) * kWave + lane];
                 // first local column with j = jl*W + w >= i (0 for a full matrix)
@@ -365,8 +380,10 @@ __global__ void __launch_bounds__(W * kWave) panel_step_kernel(const PanelParams
                     }
                 }
             }
+            PN_MARK(4)
         }
         __syncthreads();   // the U staging area is reused by the gather below
+        PN_MARK(1)
         // the Metropolis uniform when its word lies past the last row block
         if (!no_update && (aw >> 2) >= (uint32_t)(npanels * (kPanelRows / 4)) && w == 0) {
             smcmc_u32x4 blk = smcmc_draw_block(p.seed, gid, step, aw >> 2, SMCMC_STREAM_STEP);
@@ -617,6 +634,7 @@ __global__ void __launch_bounds__(W * kWave) panel_step_kernel(const PanelParams
             lsum = outside ? -1E+30 : lsum;
         }
 
+        PN_MARK(5)
         // ---- wavefront 0: StepRMS, Metropolis test (TSimpleMCMC.H:397-463) ----
         if (w == 0) {
             if (p.step_rms_window > 0) {
@@ -679,8 +697,17 @@ __global__ void __launch_bounds__(W * kWave) panel_step_kernel(const PanelParams
             }
             if (w == 0) p.save_logl[slot * (W == 4 ? NPl : NP) + chain] = logl;
         }
+        PN_MARK(6)
         __syncthreads();                           // x is final before the next step reads x[0] / its columns
+        PN_MARK(7)
     }
+#ifdef PANEL_PROFILE
+    if (group == 0 && lane == 0 && p.nsteps >= 8)
+        printf("panel_step_kernel W=%d D=%d wavefront %d, cycles per step: update+x load %llu | barriers %llu | normals %llu | U copy %llu | "
+               "rows %llu | gather+likelihood %llu | verdict+commit %llu | last barrier %llu\n", W, D, w,
+               tsec[0] / p.nsteps, tsec[1] / p.nsteps, tsec[2] / p.nsteps, tsec[3] / p.nsteps, tsec[4] / p.nsteps,
+               tsec[5] / p.nsteps, tsec[6] / p.nsteps, tsec[7] / p.nsteps);
+#endif
 
     if (active && w == 0) {
         lf[SMCMC_LANE_LOGL * NP] = logl;

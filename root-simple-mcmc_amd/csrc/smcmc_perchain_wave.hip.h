@@ -84,10 +84,10 @@ __device__ __forceinline__ void pw_fetch_all(const double* arr, double (&v)[(DMA
     }
 }
 template <int DMAX>
-__device__ __forceinline__ double pw_sum_lds(const double* arr, int D) {
+__device__ __forceinline__ double pw_sum_lds(const double* arr, int D, double s0 = 0.0) {
     double v[(DMAX + 1) / 2 * 2];
     pw_fetch_all<DMAX>(arr, v);
-    double s = 0.0;
+    double s = s0;
 #pragma unroll
     for (int i0 = 0; i0 < DMAX; i0 += 8) {
         if (i0 < D) {                   // wave-uniform; the chunk's entries from D on are +0.0
@@ -99,11 +99,11 @@ __device__ __forceinline__ double pw_sum_lds(const double* arr, int D) {
 }
 // t: this lane's term; lanes from n on contribute nothing.  scratch: kWave doubles of LDS, 16-byte aligned.
 template <int DMAX>
-__device__ __forceinline__ double pw_ordered_sum(double t, int n, double* scratch) {
+__device__ __forceinline__ double pw_ordered_sum(double t, int n, double* scratch, double s0 = 0.0) {
     __syncthreads();
     scratch[threadIdx.x] = ((int)threadIdx.x < n) ? t : 0.0;
     __syncthreads();
-    return pw_sum_lds<DMAX>(scratch, n);
+    return pw_sum_lds<DMAX>(scratch, n, s0);
 }
 
 // log L of the point in LDS (p[0 .. D)), in the reference's summation order: the arithmetic of serial_loglike<LIKE, true>
@@ -140,8 +140,28 @@ __device__ __forceinline__ double pw_loglike(const double* p, double pi, int D, 
                 for (; j < D; ++j) lsum -= h * erow[j] * p[j];
             }
         }
+    } else if constexpr (LIKE == SMCMC_LIKE_ASYM) {
+        // TAsymLogLikelihood.H:20-31: logL += p[i] * (p[i] < 0 ? like[1] : like[0]), i ascending
+        lsum = pw_ordered_sum<DMAX>((pi < 0.0) ? pi * like[1] : pi * like[0], D, scratch);
+    } else if constexpr (LIKE == SMCMC_LIKE_HORRIFIC) {
+        // THorrificLogLikelihood.H:26-38 (the arithmetic of serial_loglike<HORRIFIC, true>)
+        const bool outside = __any(((int)threadIdx.x < D) && (__builtin_fabs(pi) > 1.0)) != 0;
+        lsum = pw_ordered_sum<DMAX>(pi, D, scratch);
+        const double sigma = 0.01;
+        lsum /= __builtin_sqrt(D * 4.0 / 12.0);
+        lsum = -0.5 * lsum * lsum / sigma / sigma;
+        lsum = outside ? -1E+30 : lsum;
+    } else if constexpr (LIKE == SMCMC_LIKE_CONSTRAINED) {
+        // example4/TConstrainedLikelihood.H:26-46; like = {SummedValues, SummedConstraint, Expected[D], Prior[D]}
+        double sum = pw_ordered_sum<DMAX>(pi, D, scratch);
+        sum = (sum - like[0]) / like[1];
+        lsum -= 0.5 * sum * sum;
+        const int il = ((int)threadIdx.x < D) ? (int)threadIdx.x : 0;
+        double v = pi - like[2 + il];
+        v /= like[2 + D + il];
+        lsum = pw_ordered_sum<DMAX>(-(0.5 * v * v), D, scratch, lsum);     // x - t and x + (-t) are the same rounding
     } else {
-        static_assert(LIKE == SMCMC_LIKE_ROSENBROCK, "the wave kernel serves ISO_GAUSS, QUADFORM and ROSENBROCK");
+        static_assert(LIKE == SMCMC_LIKE_ROSENBROCK, "the likelihoods the wave kernel serves");
         // THardLogLikelihood.H:57-67: logL -= a a + 100 b b with a = 1 - p[i], b = p[i + 1] - p[i]^2, i ascending:
         // lane i its own term (its neighbour's coordinate by a lane shift), the terms subtracted in order
         const double rb = like[0];
@@ -595,7 +615,8 @@ __global__ void __launch_bounds__(kWave) perchain_wave_kernel(const PerChainPara
 
 // the likelihoods the wave kernel serves
 inline bool perchain_wave_serves(int like) {
-    return like == SMCMC_LIKE_ISO_GAUSS || like == SMCMC_LIKE_QUADFORM || like == SMCMC_LIKE_ROSENBROCK;
+    return like == SMCMC_LIKE_ISO_GAUSS || like == SMCMC_LIKE_QUADFORM || like == SMCMC_LIKE_ROSENBROCK ||
+           like == SMCMC_LIKE_ASYM || like == SMCMC_LIKE_HORRIFIC || like == SMCMC_LIKE_CONSTRAINED;
 }
 
 hipError_t launch_perchain_wave(const PerChainParams& p, const PerChainRecord& rec, int like, hipStream_t stream);

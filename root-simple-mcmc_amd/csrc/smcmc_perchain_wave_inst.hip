@@ -32,6 +32,9 @@ hipError_t launch_perchain_wave(const PerChainParams& p, const PerChainRecord& r
         case SMCMC_LIKE_ISO_GAUSS: return go_wave_like<SMCMC_LIKE_ISO_GAUSS>(p, rec, s);
         case SMCMC_LIKE_QUADFORM: return go_wave_like<SMCMC_LIKE_QUADFORM>(p, rec, s);
         case SMCMC_LIKE_ROSENBROCK: return go_wave_like<SMCMC_LIKE_ROSENBROCK>(p, rec, s);
+        case SMCMC_LIKE_ASYM: return go_wave_like<SMCMC_LIKE_ASYM>(p, rec, s);
+        case SMCMC_LIKE_HORRIFIC: return go_wave_like<SMCMC_LIKE_HORRIFIC>(p, rec, s);
+        case SMCMC_LIKE_CONSTRAINED: return go_wave_like<SMCMC_LIKE_CONSTRAINED>(p, rec, s);
         default: return hipErrorInvalidValue;
     }
 }

@@ -31,6 +31,21 @@ def test_bench_line_has_the_contract_fields(gpu):
     assert abs(out["value"] - 4096 * out["config"]["window"] * 1e3 / out["ms_per_step"]) < 1e-6 * out["value"]
 
 
+@pytest.mark.gpu
+def test_bench_config_5_line(gpu):
+    """`bench.py --config c5`: the sharded TSimpleHMC config through distributed.run_windows over HmcBackend, one rank."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "c5", "--steps", "2", "--warmup", "1",
+                        "--chains", "1024", "--dim", "80", "--window", "4"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["unit"] == "trajectories/s" and out["config"]["baseline_config"] == 5 and out["n_gpus"] == 1
+    assert out["covariance_updates"] >= 1 and 0.0 < out["accept_rate"] <= 1.0
+    assert abs(out["value"] - 1024 * 4 * 1e3 / out["ms_per_step"]) < 1e-6 * out["value"]
+    assert out["roofline"]["bound"] == "mfma" and out["roofline"]["frac"] > 0.0
+
+
 # ---- `python bench.py --gpus N` launches its own ranks (no GPU needed for the logic) ----
 def test_rank_environments(smcmc):
     envs = smcmc.distributed.rank_environments(4, 29511, {"PATH": "/bin", "WORLD_SIZE": "9"})

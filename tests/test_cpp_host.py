@@ -445,8 +445,8 @@ def test_step_loop_driver_compiles(smcmc, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dim,cycles,steps", [(5, 3, 700), (50, 2, 450)])
-def test_run_ahead_step_is_the_same_chain(gpu, tmp_path, dim, cycles, steps):
+@pytest.mark.parametrize("dim,cycles,steps,chains", [(5, 3, 700, 1), (50, 2, 450, 1), (12, 2, 300, 5)])
+def test_run_ahead_step_is_the_same_chain(gpu, tmp_path, dim, cycles, steps, chains):
     """TSimpleMCMC::Step() running ahead of its caller (one launch of 16 ... 2048 recorded steps, served call by call;
     setters / UpdateProposal() / SaveStep(true) rewind to a snapshot and replay) against Step() as one launch per call:
     the SimpleMCMC.C schedule -- per-step SaveStep(false), the getters the driver prints, UpdateProposal() and the
@@ -455,8 +455,8 @@ def test_run_ahead_step_is_the_same_chain(gpu, tmp_path, dim, cycles, steps):
     outs = []
     for ahead in (0, 1):
         out = tmp_path / f"tree{ahead}.csv"
-        r = subprocess.run([exe, str(dim), str(cycles), str(steps), "1", str(ahead), str(out)], capture_output=True, text=True,
-                           timeout=600)
+        r = subprocess.run([exe, str(dim), str(cycles), str(steps), "1", str(ahead), str(out)] + ([str(chains)] if chains > 1 else []),
+                           capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout + r.stderr
         assert f"run_ahead {ahead}" in r.stdout
         outs.append((open(out).read(), r.stdout.split("moved")[1].split("run_ahead")[0] + r.stdout.split("printed")[1]))

@@ -36,8 +36,7 @@ def _make(gpu, oracle, dim, n, kind=0, which=None, seed=20240607, offset=0, x0=N
     e = gpu.Engine(dim, n, likelihood=kind, likelihood_params=prm, seed=seed, chain_offset=offset,
                    mode=gpu.MODE_PER_CHAIN)
     e.set_param("PERCHAIN_WAVE", KERNEL["wave"])
-    if kind in (0, 1, 2):
-        assert e.get_param("PERCHAIN_WAVE") == KERNEL["wave"]
+    assert e.get_param("PERCHAIN_WAVE") == KERNEL["wave"]       # every built-in likelihood runs on either kernel
     which = list(range(n)) if which is None else list(which)
     chains = {c: oracle.Chain(dim, kind=kind, params=prm, seed=seed, chain_id=offset + c) for c in which}
     if setup:

@@ -143,6 +143,8 @@ struct smcmc_engine {
     int pc_wave = -1;              // SMCMC_P_PERCHAIN_WAVE: -1 automatic, 0 / 1 one chain per lane / per wavefront
     smcmc::PerChainRecord pc_rec = {nullptr, 0, 0};   // the per-step record of the launch in progress (smcmc_step_recorded)
     double* d_pc_rec = nullptr;    // its device buffer
+    double* d_pc_stage = nullptr;  // the fallback ladder's staging records (pc_host_ladder), allocated at the first ladder
+    int32_t* d_pc_stage_chains = nullptr;
     // smcmc_snapshot / smcmc_rollback: a copy of the ensemble's state on the device (SMCMC_MODE_PER_CHAIN)
     void* snap[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     uint32_t snap_total_steps = 0;
@@ -805,47 +807,74 @@ inline hipError_t pc_put_tiled(double* base, int chain, int rows, int count, con
 // UpdateProposal() call, to be simply done).
 int pc_host_ladder(smcmc_engine* h, bool explicit_update) {
     const int D = h->dim, npk = D * (D + 1) / 2;
-    const size_t NP = (size_t)h->npad;
-    std::vector<int32_t> status(NP);
+    const size_t NP = (size_t)h->npad, stride = smcmc::pc_stage_stride(D);
+    std::vector<int32_t> status(NP), flagged;
     HIP_TRY(h, hipMemcpy(status.data(), h->d_lane_i32 + (size_t)SMCMC_LANE_UPDATE_STATUS * NP, NP * sizeof(int32_t),
                          hipMemcpyDeviceToHost));
-    std::vector<double> lf(SMCMC_LANE_F64_COUNT_), packed(npk), ut;
-    std::vector<int32_t> li(SMCMC_LANE_I32_COUNT_);
     for (int c = 0; c < h->nchains; ++c) {
         if (status[c] == kPcOk || status[c] == kPcResume) continue;
         if (status[c] == kPcInvalidTrace) return status_of(h, UpdateStatus::InvalidTrace);     // :1025-1028
-        SharedProposal T(*h->prop);                      // the settings; the state comes from the chain
-        HIP_TRY(h, pc_get_column(h->d_lane_f64, NP, c, SMCMC_LANE_F64_COUNT_, lf.data()));
-        HIP_TRY(h, pc_get_column(h->d_lane_i32, NP, c, SMCMC_LANE_I32_COUNT_, li.data()));
-        HIP_TRY(h, pc_get_tiled(h->d_pc_cov, c, npk, npk, packed.data()));
-        HIP_TRY(h, pc_get_column(h->d_pc_centre, NP, c, D, T.centre.data()));
-        HIP_TRY(h, pc_get_column(h->d_pc_last, NP, c, D, T.lastPoint.data()));
-        for (int i = 0; i < D; ++i)
-            for (int j = 0; j <= i; ++j) T.C(i, j) = T.C(j, i) = packed[(size_t)i * (i + 1) / 2 + j];
-        T.initialized = true;
-        T.centreTrials = lf[SMCMC_LANE_CENTER_TRIALS]; T.covTrials = lf[SMCMC_LANE_COVARIANCE_TRIALS];
-        T.sigma = lf[SMCMC_LANE_SIGMA]; T.sigmaTrace = lf[SMCMC_LANE_SIGMA_TRACE];
-        T.acceptance = lf[SMCMC_LANE_ACCEPTANCE]; T.acceptanceTrials = lf[SMCMC_LANE_ACCEPTANCE_TRIALS];
-        T.successes = li[SMCMC_LANE_SUCCESSES]; T.nextUpdate = li[SMCMC_LANE_NEXT_UPDATE];
-        T.updateCount = li[SMCMC_LANE_UPDATE_COUNT];
-        const int st = status_of(h, T.finishUpdateOnHost(1.0));
-        if (st) return st;
-        for (int i = 0; i < D; ++i)
-            for (int j = 0; j <= i; ++j) packed[(size_t)i * (i + 1) / 2 + j] = T.cov[(size_t)i * D + j];
-        pc_pack_decomp(T, ut);
-        HIP_TRY(h, pc_put_tiled(h->d_pc_cov, c, npk, npk, packed.data()));
-        HIP_TRY(h, pc_put_tiled(h->d_pc_ut, c, D * D, D * D, ut.data()));
-        HIP_TRY(h, pc_put_column(h->d_pc_centre, NP, c, D, T.centre.data()));
-        lf[SMCMC_LANE_CENTER_TRIALS] = T.centreTrials; lf[SMCMC_LANE_COVARIANCE_TRIALS] = T.covTrials;
-        lf[SMCMC_LANE_SIGMA] = T.sigma; lf[SMCMC_LANE_SIGMA_TRACE] = T.sigmaTrace;
-        lf[SMCMC_LANE_ACCEPTANCE] = T.acceptance; lf[SMCMC_LANE_ACCEPTANCE_TRIALS] = T.acceptanceTrials;
-        li[SMCMC_LANE_SUCCESSES] = T.successes; li[SMCMC_LANE_NEXT_UPDATE] = T.nextUpdate;
-        li[SMCMC_LANE_UPDATE_COUNT] = T.updateCount; li[SMCMC_LANE_LAST_UPDATE_PATH] = T.lastPath;
-        li[SMCMC_LANE_DECOMP_FULL] = T.decompFull ? 1 : 0;
-        if (T.lastPath == 4) li[SMCMC_LANE_TRIALS] = 0;    // the ladder ended in ResetProposal (:1389, 1405)
-        li[SMCMC_LANE_UPDATE_STATUS] = explicit_update ? kPcOk : kPcResume;
-        HIP_TRY(h, pc_put_column(h->d_lane_f64, NP, c, SMCMC_LANE_F64_COUNT_, lf.data()));
-        HIP_TRY(h, pc_put_column(h->d_lane_i32, NP, c, SMCMC_LANE_I32_COUNT_, li.data()));
+        flagged.push_back(c);
+    }
+    // the flagged chains in batches through one staging buffer: one gather launch, one copy each way, one scatter launch
+    // per batch (chain by chain this was ten strided copies of 8-byte rows per chain)
+    const size_t batch_max = std::max<size_t>(1, std::min<size_t>(4096, ((size_t)256 << 20) / (stride * sizeof(double))));
+    if (!h->d_pc_stage) {
+        HIP_TRY(h, hipMalloc(&h->d_pc_stage, batch_max * stride * sizeof(double)));
+        HIP_TRY(h, hipMalloc(&h->d_pc_stage_chains, batch_max * sizeof(int32_t)));
+    }
+    std::vector<double> stage, ut;
+    for (size_t b0 = 0; b0 < flagged.size(); b0 += batch_max) {
+        const int nb = (int)std::min(batch_max, flagged.size() - b0);
+        stage.resize((size_t)nb * stride);
+        HIP_TRY(h, hipMemcpyAsync(h->d_pc_stage_chains, flagged.data() + b0, (size_t)nb * sizeof(int32_t), hipMemcpyHostToDevice,
+                                  h->stream));
+        smcmc::PerChainStage g;
+        g.chains = h->d_pc_stage_chains; g.stage = h->d_pc_stage; g.npad = h->npad; g.dim = D;
+        g.lane_f64 = h->d_lane_f64; g.lane_i32 = h->d_lane_i32;
+        g.cov = h->d_pc_cov; g.ut = h->d_pc_ut; g.centre = h->d_pc_centre; g.last = h->d_pc_last;
+        hipError_t e = smcmc::launch_perchain_stage(g, nb, false, h->stream);
+        if (e != hipSuccess) return fail(h, SMCMC_ERR_HIP, std::string("per-chain ladder gather: ") + hipGetErrorString(e));
+        HIP_TRY(h, hipMemcpyAsync(stage.data(), h->d_pc_stage, stage.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        for (int q = 0; q < nb; ++q) {
+            double* lf = stage.data() + (size_t)q * stride;
+            double* li = lf + SMCMC_LANE_F64_COUNT_;          // (the 32-bit lane values, as doubles)
+            double* packed = li + SMCMC_LANE_I32_COUNT_;
+            double* utq = packed + npk;
+            double* centre = utq + (size_t)D * D;
+            double* last = centre + D;
+            SharedProposal T(*h->prop);                      // the settings; the state comes from the chain
+            std::copy(centre, centre + D, T.centre.begin());
+            std::copy(last, last + D, T.lastPoint.begin());
+            for (int i = 0; i < D; ++i)
+                for (int j = 0; j <= i; ++j) T.C(i, j) = T.C(j, i) = packed[(size_t)i * (i + 1) / 2 + j];
+            T.initialized = true;
+            T.centreTrials = lf[SMCMC_LANE_CENTER_TRIALS]; T.covTrials = lf[SMCMC_LANE_COVARIANCE_TRIALS];
+            T.sigma = lf[SMCMC_LANE_SIGMA]; T.sigmaTrace = lf[SMCMC_LANE_SIGMA_TRACE];
+            T.acceptance = lf[SMCMC_LANE_ACCEPTANCE]; T.acceptanceTrials = lf[SMCMC_LANE_ACCEPTANCE_TRIALS];
+            T.successes = (int)li[SMCMC_LANE_SUCCESSES]; T.nextUpdate = (int)li[SMCMC_LANE_NEXT_UPDATE];
+            T.updateCount = (int)li[SMCMC_LANE_UPDATE_COUNT];
+            const int st = status_of(h, T.finishUpdateOnHost(1.0));
+            if (st) return st;
+            for (int i = 0; i < D; ++i)
+                for (int j = 0; j <= i; ++j) packed[(size_t)i * (i + 1) / 2 + j] = T.cov[(size_t)i * D + j];
+            pc_pack_decomp(T, ut);
+            std::copy(ut.begin(), ut.end(), utq);
+            std::copy(T.centre.begin(), T.centre.begin() + D, centre);
+            lf[SMCMC_LANE_CENTER_TRIALS] = T.centreTrials; lf[SMCMC_LANE_COVARIANCE_TRIALS] = T.covTrials;
+            lf[SMCMC_LANE_SIGMA] = T.sigma; lf[SMCMC_LANE_SIGMA_TRACE] = T.sigmaTrace;
+            lf[SMCMC_LANE_ACCEPTANCE] = T.acceptance; lf[SMCMC_LANE_ACCEPTANCE_TRIALS] = T.acceptanceTrials;
+            li[SMCMC_LANE_SUCCESSES] = T.successes; li[SMCMC_LANE_NEXT_UPDATE] = T.nextUpdate;
+            li[SMCMC_LANE_UPDATE_COUNT] = T.updateCount; li[SMCMC_LANE_LAST_UPDATE_PATH] = T.lastPath;
+            li[SMCMC_LANE_DECOMP_FULL] = T.decompFull ? 1 : 0;
+            if (T.lastPath == 4) li[SMCMC_LANE_TRIALS] = 0;    // the ladder ended in ResetProposal (:1389, 1405)
+            li[SMCMC_LANE_UPDATE_STATUS] = explicit_update ? kPcOk : kPcResume;
+        }
+        HIP_TRY(h, hipMemcpyAsync(h->d_pc_stage, stage.data(), stage.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        e = smcmc::launch_perchain_stage(g, nb, true, h->stream);
+        if (e != hipSuccess) return fail(h, SMCMC_ERR_HIP, std::string("per-chain ladder scatter: ") + hipGetErrorString(e));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));     // pageable source
     }
     return SMCMC_OK;
 }
@@ -1251,7 +1280,7 @@ int smcmc_destroy(smcmc_engine* h) {
     (void)hipFree(h->d_centre); (void)hipFree(h->d_cov); (void)hipFree(h->d_decomp); (void)hipFree(h->d_scal);
     (void)hipFree(h->d_ring); (void)hipFree(h->d_ring_logl);
     (void)hipFree(h->d_pc_cov); (void)hipFree(h->d_pc_ut); (void)hipFree(h->d_pc_centre); (void)hipFree(h->d_pc_last);
-    (void)hipFree(h->d_pc_tmpl); (void)hipFree(h->d_pc_flag);
+    (void)hipFree(h->d_pc_tmpl); (void)hipFree(h->d_pc_flag); (void)hipFree(h->d_pc_stage); (void)hipFree(h->d_pc_stage_chains);
     (void)hipHostFree(h->h_scal);
     if (h->status_event) (void)hipEventDestroy(h->status_event);
     delete h->prop;

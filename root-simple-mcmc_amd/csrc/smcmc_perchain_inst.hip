@@ -102,6 +102,37 @@ hipError_t launch_perchain_broadcast_rows(double* dst, const double* values_devi
     return hipGetLastError();
 }
 
+// The host's fallback ladder works on whole chains: the flagged chains' columns of every image go to / come from one
+// contiguous staging record per chain (PerChainStage: the layout), one workgroup per chain.
+__global__ void __launch_bounds__(256) perchain_stage_kernel(PerChainStage g, int scatter) {
+    const size_t chain = (size_t)g.chains[blockIdx.x], NP = g.npad;
+    const int D = g.dim, npk = D * (D + 1) / 2;
+    double* rec = g.stage + (size_t)blockIdx.x * pc_stage_stride(D);
+    double* f64 = rec, *i32 = f64 + SMCMC_LANE_F64_COUNT_, *cov = i32 + SMCMC_LANE_I32_COUNT_, *ut = cov + npk,
+            *centre = ut + D * D, *last = centre + D;
+    for (int k = threadIdx.x; k < SMCMC_LANE_F64_COUNT_; k += blockDim.x) {
+        if (scatter) g.lane_f64[(size_t)k * NP + chain] = f64[k]; else f64[k] = g.lane_f64[(size_t)k * NP + chain];
+    }
+    for (int k = threadIdx.x; k < SMCMC_LANE_I32_COUNT_; k += blockDim.x) {
+        if (scatter) g.lane_i32[(size_t)k * NP + chain] = (int32_t)i32[k]; else i32[k] = (double)g.lane_i32[(size_t)k * NP + chain];
+    }
+    for (int k = threadIdx.x; k < npk; k += blockDim.x) {
+        if (scatter) g.cov[pc_tile_index(k, chain, npk)] = cov[k]; else cov[k] = g.cov[pc_tile_index(k, chain, npk)];
+    }
+    for (int k = threadIdx.x; k < D; k += blockDim.x) {
+        if (scatter) g.centre[(size_t)k * NP + chain] = centre[k];
+        else { centre[k] = g.centre[(size_t)k * NP + chain]; last[k] = g.last[(size_t)k * NP + chain]; }
+    }
+    if (scatter)
+        for (int k = threadIdx.x; k < D * D; k += blockDim.x) g.ut[pc_tile_index(k, chain, D * D)] = ut[k];
+}
+
+hipError_t launch_perchain_stage(const PerChainStage& g, int nflagged, bool scatter, hipStream_t s) {
+    if (nflagged < 1 || g.dim < 1 || g.dim > kPcMaxDim || !g.chains || !g.stage) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(perchain_stage_kernel, dim3(nflagged), dim3(256), 0, s, g, scatter ? 1 : 0);
+    return hipGetLastError();
+}
+
 hipError_t launch_perchain_broadcast(const PerChainBroadcast& p, hipStream_t s) {
     if (p.dim < 1 || p.dim > kPcMaxDim || p.nchains < 1 || p.nchains > p.npad) return hipErrorInvalidValue;
     hipLaunchKernelGGL(perchain_broadcast_kernel, dim3((p.nchains + 255) / 256), dim3(256), 0, s, p);

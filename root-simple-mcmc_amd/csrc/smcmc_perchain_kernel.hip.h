@@ -712,4 +712,18 @@ hipError_t launch_perchain_broadcast(const PerChainBroadcast& p, hipStream_t str
 hipError_t launch_perchain_broadcast_rows(double* dst, const double* values_device, int rows, int nchains, size_t npad, bool tiled,
                                           hipStream_t stream);
 
+// One flagged chain's staging record for the host's fallback ladder (perchain_stage_kernel): the lane scalars (the
+// 32-bit ones as doubles), the packed covariance, the decomposition image (scatter only), the centre, the last point.
+__host__ __device__ inline size_t pc_stage_stride(int D) {
+    return (size_t)SMCMC_LANE_F64_COUNT_ + SMCMC_LANE_I32_COUNT_ + (size_t)D * (D + 1) / 2 + (size_t)D * D + 2 * (size_t)D;
+}
+struct PerChainStage {
+    const int32_t* chains;     // [nflagged] chain indices
+    double* stage;             // [nflagged][pc_stage_stride(dim)]
+    int npad, dim;
+    double* lane_f64; int32_t* lane_i32;
+    double* cov; double* ut; double* centre; double* last;
+};
+hipError_t launch_perchain_stage(const PerChainStage& g, int nflagged, bool scatter, hipStream_t s);
+
 }  // namespace smcmc

@@ -237,6 +237,34 @@ def test_the_fallback_ladder_inside_a_launch(gpu, oracle):
     _same(e, chains, "and on")
 
 
+def test_the_fallback_ladder_for_thousands_of_chains_at_once(gpu, oracle):
+    """Every chain of a 5 000-chain ensemble stops for the host's ladder in the same launches: the flagged chains go
+    through the staging records in batches (4 096 + 904 here; pc_host_ladder), and the sampled chains -- first and last
+    of each batch -- are still the reference chains.  (Chain by chain with strided copies this took minutes.)"""
+    import time
+    dim, n = 6, 5000
+    e, chains = _make(gpu, oracle, dim, n, 0, which=(0, 63, 4095, 4096, 4999))
+    _step(e, chains, 50)
+    bad = np.eye(dim)
+    bad[0, 1] = bad[1, 0] = 1.0 + 1e-3
+    e.SetCovariance(bad)
+    for ch in chains.values():
+        ch.set_covariance(bad)
+    _both(e, chains, "SetCovarianceWindow", "set_covariance_window", 10 ** 6)
+    _both(e, chains, "SetCovarianceTrials", "set_covariance_trials", 1e6)
+    _both(e, chains, "SetNextUpdate", "set_next_update", 3)
+    t0 = time.perf_counter()
+    e.Step(60)
+    e.sync()
+    assert time.perf_counter() - t0 < 30.0
+    for ch in chains.values():
+        ch.run_quiet(60)
+    assert np.all(e.lane("last_update_path") >= 1), "the ladder must have run in every chain"
+    _same(e, chains, "after the ladder")
+    _step(e, chains, 100)
+    _same(e, chains, "and on")
+
+
 def test_the_fallback_ladder_on_the_last_step_of_a_launch(gpu, oracle):
     """The same ladder driven one step per launch (what TSimpleMCMC_amd.H::Step() does for a single chain): every ladder
     event then lands on the LAST step of its launch, the chain stops with its step counter already at the launch's

@@ -356,8 +356,11 @@ __global__ void __launch_bounds__(W * kWave) panel_step_kernel(const PanelParams
             lds_cptr_f64 up = (lds_cptr_f64)(ulds + w * (kPanelRows * CW));
             asm volatile("" : "+v"(up));   // LDS addresses live in vector registers
             // (tools/micro/panelprof.py: this loop is 187 000 of the 292 000 cycles of a config-3 step, ~400 cycles per
-            // 16-column piece against 128 of arithmetic -- the four wavefronts' broadcast reads queue at the CU's one LDS
-            // pipe.  Products first / the next piece's reads issued behind them / additions last was measured: 207 000.)
+            // 16-column piece against 128 of arithmetic.  Measured and not kept, all bit-identical (profiles/r04_notes.md
+            // section 5): products first / the next piece's reads behind them / additions last: 207 000; the panel cut where
+            // the first live piece changes, pieces compile-time, the next piece's reads in flight in a second register
+            // set: 161 000 here but the rest of the step slower by as much (512 registers, more scratch), and the
+            // eight-wavefront kernel 1.02 instead of 0.78 ms per step.)
             for (int i = i0; i < i1; ++i) {
                 const double sr = sigma * rbuf[(i - i0) * kWave + lane];
                 // first local column with j = jl*W + w >= i (0 for a full matrix)

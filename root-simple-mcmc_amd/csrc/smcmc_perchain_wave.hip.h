@@ -188,6 +188,10 @@ __global__ void __launch_bounds__(kWave) perchain_wave_kernel(const PerChainPara
     __shared__ __attribute__((aligned(16))) double zv[kWave];   // sigma r_i of the step, for every lane to read
     __shared__ __attribute__((aligned(16))) double sv[kWave];   // the terms of an ordered sum
     __shared__ double ps[kWave];         // QUADFORM: the proposal, for the walk over the entries of Error
+    // One step's record (PerChainRecord) is put together here and leaves in three coalesced stores; behind it one slot
+    // per lane for the writes of the elements that are not on the diagonal (so that no write needs a predicate).
+    constexpr int kRecDump = 3 * kWave + 16;
+    __shared__ __attribute__((aligned(16))) double recl[kRecDump + kWave];
     __shared__ __attribute__((aligned(16))) double ntab[384];   // tables of the normal transform (as in step_kernel)
 
     const int lane = threadIdx.x;
@@ -240,7 +244,8 @@ __global__ void __launch_bounds__(kWave) perchain_wave_kernel(const PerChainPara
     // the chain's state on chip
     double xi = p.x[own], ci = p.centre[own], lasti = p.last_point[own], xpi = p.proposed[own];
     double cov[NE];
-    uint32_t ij[NE];                     // (row << 8 | column) of element k = lane + 64 r
+    uint32_t ij[NE];                     // (row << 8 | column) of element k = lane + 64 r; bits 16..: where the element goes in
+                                         // recl when a step is recorded (its slot of the diagonal, or the lane's dump slot)
     // Which of this lane's registers hold an element at all, and which a diagonal one: as BIT masks, tested where they
     // are used.  (As conditions on `lane + 64 r < npk` they are loop-invariant lane masks: the compiler keeps all 2 NE of
     // them in SGPR pairs across the step loop, runs out of SGPRs and moves them through VGPR lanes at every use --
@@ -256,7 +261,7 @@ __global__ void __launch_bounds__(kWave) perchain_wave_kernel(const PerChainPara
             valid_bits |= 1u << r;
             if (i == j) diag_bits |= 1u << r;
         }
-        ij[r] = (uint32_t)(i << 8 | j);
+        ij[r] = (uint32_t)(i << 8 | j) | (uint32_t)((k < npk && i == j) ? 2 * D + i : kRecDump + lane) << 16;
         cov[r] = (k < npk) ? p.cov[pc_tile_index(k, (size_t)chain, npk)] : 0.0;
     }
     const int colj = lane * (lane + 1) / 2;    // start of this lane's column of the decomposition
@@ -412,7 +417,7 @@ __global__ void __launch_bounds__(kWave) perchain_wave_kernel(const PerChainPara
                     double da[NE], db[NE];
 #pragma unroll
                     for (int r = 0; r < NE; ++r) {
-                        da[r] = dv[ij[r] >> 8];
+                        da[r] = dv[(ij[r] >> 8) & 255u];
                         db[r] = dv[ij[r] & 255u];
                     }
 #pragma unroll
@@ -541,28 +546,25 @@ __global__ void __launch_bounds__(kWave) perchain_wave_kernel(const PerChainPara
                 if (mine) p.save_x[(slot * (size_t)D + (size_t)lane) * NP + chain] = xi;
                 if (lane == 0) p.save_logl[slot * NP + chain] = logl;
             }
-            if (rec.rec != nullptr && chain == rec.chain) {
+            if (rec.rec != nullptr && chain == rec.chain) {          // (one chain per workgroup: the same for all 64 lanes)
                 double* r = rec.rec + (size_t)(tstep - p.step0 - 1u) * rec.stride;
                 if (mine) {
-                    r[lane] = xi;
-                    r[D + lane] = xpi;
+                    recl[lane] = xi;
+                    recl[D + lane] = xpi;
                 }
-                {
-                    uint32_t db = diag_bits;
-                    asm volatile("" : "+v"(db));
 #pragma unroll
-                    for (int q = 0; q < NE; ++q)
-                        if ((db >> q) & 1u) r[2 * D + (ij[q] & 255u)] = cov[q];
-                }
-                const double trace = 0.0;     // (the reader sums the diagonal)
+                for (int q = 0; q < NE; ++q) recl[ij[q] >> 16] = cov[q];   // the diagonal to [2 D, 3 D), everything else to the dump slot
                 if (lane == 0) {
-                    double* s = r + 3 * D;
+                    double* s = recl + 3 * D;
                     s[kPcRecLogl] = logl; s[kPcRecLoglProposed] = logl_prop; s[kPcRecStepRms] = step_rms;
                     s[kPcRecLastAccept] = last_accept; s[kPcRecTrials] = trials; s[kPcRecSuccesses] = succ;
                     s[kPcRecNextUpdate] = next_update; s[kPcRecAcceptance] = acc_rate; s[kPcRecAcceptanceTrials] = acc_trials;
                     s[kPcRecSigma] = sigma; s[kPcRecCenterTrials] = centre_trials; s[kPcRecCovarianceTrials] = cov_trials;
-                    s[kPcRecTrace] = trace; s[kPcRecTotalSteps] = (double)tstep; s[kPcRecStatus] = status;
+                    s[kPcRecTrace] = 0.0;     // (the reader sums the diagonal)
+                    s[kPcRecTotalSteps] = (double)tstep; s[kPcRecStatus] = status;
                 }
+                __syncthreads();
+                for (int k = lane; k < rec.stride; k += kWave) r[k] = recl[k];
             }
             live = tstep < p.target_step;
             PW_MARK(7)

@@ -27,6 +27,9 @@ __device__ __forceinline__ double rl(double v, int i) {
 // MODE 0: b128 broadcast, reads only   1: b128 broadcast + arithmetic   2: b64 broadcast reads only
 //      3: b128 per-lane addresses, reads only   4: b64 per-lane, reads only   5: per-lane b64 + readlane + arithmetic
 //      6: arithmetic alone (16 mul + 16 add per piece, no reads)
+//      7: b128 broadcast, the NEXT piece's reads issued before this piece's arithmetic (two register sets), mul / add adjacent
+//      8: as 7, all 16 products first, then the 16 additions
+//      9: as 7, product k + 1 issued before addition k
 template <int MODE, int NW>
 __global__ void __launch_bounds__(NW * 64) k(double* out, int reps, unsigned long long* cycles) {
     __shared__ __attribute__((aligned(16))) double lds[NW * kRow];
@@ -42,7 +45,7 @@ __global__ void __launch_bounds__(NW * 64) k(double* out, int reps, unsigned lon
     const unsigned long long t0 = __builtin_readcyclecounter();
     for (int r = 0; r < reps; ++r) {
 #pragma unroll 1
-        for (int p = 0; p < kRow / 16; ++p) {           // one "piece": 16 doubles
+        for (int p = 0; p < (MODE >= 7 ? 0 : kRow / 16); ++p) {           // one "piece": 16 doubles
             lds_c1 a = base + p * 16;
             if constexpr (MODE == 0 || MODE == 1) {
                 f64x2 u[8];
@@ -75,9 +78,48 @@ __global__ void __launch_bounds__(NW * 64) k(double* out, int reps, unsigned lon
                     asm volatile("" : "+v"(acc[q]));
                 }
                 (void)l0;
-            } else {
+            } else if constexpr (MODE == 6) {
 #pragma unroll
                 for (int q = 0; q < 16; ++q) { acc[q] += sr * acc[(q + 1) & 15]; asm volatile("" : "+v"(acc[q])); }
+            }
+        }
+        if constexpr (MODE >= 7) {
+            f64x2 ua[8], ub[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) ua[q] = *(volatile lds_c2)(base + 2 * q);
+            auto arith = [&](f64x2 (&u)[8]) __attribute__((always_inline)) {
+                if constexpr (MODE == 7) {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) { acc[q] += sr * u[q / 2][q & 1]; asm volatile("" : "+v"(acc[q])); }
+                } else if constexpr (MODE == 8) {
+                    double t[16];
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) t[q] = sr * u[q / 2][q & 1];
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) { acc[q] += t[q]; asm volatile("" : "+v"(acc[q])); }
+                    __builtin_amdgcn_sched_barrier(0);
+                } else {
+                    double t = sr * u[0][0];
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        double tn = (q + 1 < 16) ? sr * u[(q + 1) / 2][(q + 1) & 1] : 0.0;
+                        asm volatile("" : "+v"(tn));
+                        acc[q] += t;
+                        asm volatile("" : "+v"(acc[q]));
+                        t = tn;
+                    }
+                }
+            };
+#pragma unroll 1
+            for (int p = 0; p < kRow / 16; p += 2) {
+                lds_c1 a1 = base + (p + 1) * 16, a2 = base + ((p + 2) & (kRow / 16 - 1)) * 16;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) ub[q] = *(volatile lds_c2)(a1 + 2 * q);
+                arith(ua);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) ua[q] = *(volatile lds_c2)(a2 + 2 * q);
+                arith(ub);
             }
         }
     }
@@ -122,5 +164,8 @@ int main() {
     BOTH(4, "8 x ds_read_b64 per-lane addresses, reads only")
     BOTH(5, "1/4 per-lane ds_read_b64 + 32 v_readlane + 16 mul + 16 add")
     BOTH(6, "16 mul + 16 add alone")
+    BOTH(7, "b128 broadcast, next piece's reads ahead, mul / add adjacent")
+    BOTH(8, "b128 broadcast, next piece's reads ahead, 16 mul then 16 add")
+    BOTH(9, "b128 broadcast, next piece's reads ahead, mul k+1 before add k")
     return 0;
 }

@@ -1,8 +1,10 @@
 import sys, numpy as np
-sys.path.insert(0, '.')
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
 from smcmc_amd_loader import load_package
 pkg = load_package()
-lib = 'root-simple-mcmc_amd/build/prof/libsmcmc_amd_prof.so'
+lib = os.path.join(ROOT, 'root-simple-mcmc_amd', 'build', 'prof', 'libsmcmc_amd_prof.so')
 names = ["loop top", "scalar half + centre", "covariance update", "trigger / last point", "Philox + normals", "proposal columns", "StepRMS sum", "likelihood, accept, record"]
 for dim in (50, 5):
     e = pkg.Engine(dim, 1, mode=pkg.MODE_PER_CHAIN, library=lib)

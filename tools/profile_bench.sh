@@ -20,5 +20,14 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pc_write -- 
 $R/root-simple-mcmc_amd/build/micro/fold_bench 20 > $O/fold_bench.txt 2>&1
 bash $R/tools/micro/fold_prof.sh $(basename $O)/fold > $O/fold_prof.txt 2>&1
 $R/root-simple-mcmc_amd/build/micro/ordered_sum > $O/ordered_sum.txt 2>&1
+# the reference-order large-dimension kernel: cycles per section (profiling build, tools/micro/build_panelprof.sh), its rates,
+# and what the CU's LDS pipe charges for the broadcast reads its row loop lives on
+python3 $R/tools/micro/panelprof.py 2>&1 | grep "cycles per step" | sort > $O/panel_sections.txt
+python3 $R/tools/panel_time.py > $O/panel_time.txt 2>&1
+$R/root-simple-mcmc_amd/build/micro/lds_bcast > $O/lds_bcast.txt 2>&1
+# the per-chain wave kernel: cycles per section (tools/micro/build_pwprof.sh), the cost of the per-step record, the drop-in loop
+python3 $R/tools/micro/pwprof.py 2>&1 | grep "cycles per step" > $O/perchain_wave_sections.txt
+python3 $R/tools/record_cost.py 2>&1 | grep "us per step" > $O/record_cost.txt
+python3 $R/tools/step_loop_time.py 2>&1 | grep steps_per_s > $O/step_loop.txt
 python3 $R/bench.py > $O/bench.json 2> $O/bench.err
 tail -1 $O/bench.json | cut -c1-300

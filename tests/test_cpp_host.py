@@ -453,13 +453,13 @@ def test_run_ahead_step_is_the_same_chain(gpu, tmp_path, dim, cycles, steps, cha
     per-cycle setters -- writes the same tree, entry for entry and bit for bit."""
     exe = _build_cpp(tmp_path, os.path.join("examples", "StepLoop_amd.C"), "step_loop.exe")
     outs = []
-    for ahead in (0, 1):
+    for ahead in (0, 1, 2):                              # 2: run-ahead on, SetRunAhead(false) after the first cycle
         out = tmp_path / f"tree{ahead}.csv"
         r = subprocess.run([exe, str(dim), str(cycles), str(steps), "1", str(ahead), str(out)] + ([str(chains)] if chains > 1 else []),
                            capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout + r.stderr
-        assert f"run_ahead {ahead}" in r.stdout
+        assert f"run_ahead {1 if ahead == 1 else 0}" in r.stdout
         outs.append((open(out).read(), r.stdout.split("moved")[1].split("run_ahead")[0] + r.stdout.split("printed")[1]))
-    assert outs[0][1] == outs[1][1]                      # moved / entries / the printed getters
-    assert outs[0][0] == outs[1][0]                      # the trees, as text: every column of every entry
+    assert outs[0][1] == outs[1][1] == outs[2][1]        # moved / entries / the printed getters
+    assert outs[0][0] == outs[1][0] == outs[2][0]        # the trees, as text: every column of every entry
     assert len(outs[0][0].splitlines()) == cycles * steps + 2

@@ -33,6 +33,7 @@ def main():
                     help="the header form of TDummyLogLikelihood (quadratic form, TDummyLogLikelihood.H:24-28) instead of the README form")
     ap.add_argument("--kernel", choices=("auto", "lane", "wave"), default="auto",
                     help="SMCMC_P_PERCHAIN_WAVE: one chain per lane (perchain_step_kernel) or per wavefront (perchain_wave_kernel)")
+    ap.add_argument("--library", default=None, help="another build of the library (an experiment)")
     ap.add_argument("--json")
     a = ap.parse_args()
     import torch
@@ -46,7 +47,7 @@ def main():
             cov = np.eye(a.dim)
             cov[0, a.dim - 1] = cov[a.dim - 1, 0] = 0.999999                     # TDummyLogLikelihood::Init(), :44-142
             kw = {"likelihood": pkg.LIKE_QUADFORM, "likelihood_params": np.linalg.inv(cov)}
-        e = pkg.Engine(a.dim, n, mode=pkg.MODE_PER_CHAIN, stream=stream.cuda_stream, **kw)
+        e = pkg.Engine(a.dim, n, mode=pkg.MODE_PER_CHAIN, stream=stream.cuda_stream, library=a.library, **kw)
         e.set_param("PERCHAIN_WAVE", {"auto": -1, "lane": 0, "wave": 1}[a.kernel])
         if a.frozen:
             e.SetCovarianceFrozen(True)

@@ -119,7 +119,13 @@ SMCMC_HD smcmc_u32x4 smcmc_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2,
  * as the fewest that pass BigCrush ("Crush-resistant"), ten their default with a safety margin.  The headline kernel
  * spends 13 blocks per chain-step, so the three rounds are 3 % of its instructions; the round function and the key
  * schedule are pinned by the Random123 known answers of the 10-round generator (tests/test_detmath.py). */
+/* Build switches of the FROZEN-DEFINITION build (tests/golden/frozen_definition_*.npz, oracle/Makefile `frozen`,
+ * root-simple-mcmc_amd/build.py build_frozen_definition): -DSMCMC_PHILOX_ROUNDS=10 -DSMCMC_NORMAL_TEXTBOOK give the draws
+ * their textbook definition -- the paper's ten rounds, r = sqrt(-2 ln u1), (cos, sin)(2 pi u2) through the <= 1 ulp
+ * functions of this header -- which no tuning of the production transform touches: one golden set that stays what it is. */
+#ifndef SMCMC_PHILOX_ROUNDS
 #define SMCMC_PHILOX_ROUNDS 7
+#endif
 SMCMC_HD smcmc_u32x4 smcmc_draw_block(uint64_t seed, uint32_t chain, uint64_t step,
                                       uint32_t block, uint32_t stream) {
     return smcmc_philox4x32_rounds(block, chain, (uint32_t)step,
@@ -420,9 +426,19 @@ static __device__ const double smcmc_angle_table_dev[128] = SMCMC_ANGLE_TABLE_IN
 #define SMCMC_AT_DEFAULT(k, c) smcmc_angle_table_host[2u * (k) + (c)]
 #endif
 
+#ifdef SMCMC_NORMAL_TEXTBOOK
+SMCMC_HD void smcmc_normal_pair(uint32_t w0, uint32_t w1, double* n0, double* n1) {
+    const double r = smcmc_sqrt_mid(-2.0 * smcmc_log_pos(smcmc_u01(w0)));
+    double sn, cs;
+    smcmc_sincos2pi_u32(w1, &sn, &cs);
+    *n0 = r * cs;
+    *n1 = r * sn;
+}
+#else
 SMCMC_HD void smcmc_normal_pair(uint32_t w0, uint32_t w1, double* n0, double* n1) {
     SMCMC_NORMAL_PAIR_BODY(SMCMC_LT_DEFAULT, SMCMC_AT_DEFAULT)
 }
+#endif
 
 /* v[i] for a run-time i without indexing memory. */
 SMCMC_HD uint32_t smcmc_select_word(smcmc_u32x4 b, uint32_t i) {

@@ -34,6 +34,39 @@ def build(force=False):
     return _LIB_PATH
 
 
+_FROZEN_LIB_PATH = os.path.join(_HERE, "_build", "libsmcmc_oracle_frozen_definition.so")
+
+
+def build_frozen_definition(force=False):
+    """The oracle compiled with -DSMCMC_PHILOX_ROUNDS=10 -DSMCMC_NORMAL_TEXTBOOK (Makefile target `frozen`)."""
+    srcs = [os.path.join(_HERE, f) for f in
+            ("smcmc_oracle.c", "ensemble_oracle.c", "hmc_oracle.c", "vaat_oracle.c", "oracle_core.h", "oracle_linalg.h")]
+    srcs.append(os.path.join(_HERE, "..", "include", "smcmc_detmath.h"))
+    stale = force or not os.path.exists(_FROZEN_LIB_PATH) or any(
+        os.path.getmtime(s) > os.path.getmtime(_FROZEN_LIB_PATH) for s in srcs if os.path.exists(s))
+    if stale:
+        subprocess.check_call(["make", "-C", _HERE, "-s", "frozen"] + (["-B"] if force else []))
+    return _FROZEN_LIB_PATH
+
+
+def frozen_definition():
+    """This module once more, bound to the frozen-definition build of the oracle: the same classes (Chain, Ensemble, ...)
+    drawing with ten Philox rounds and the textbook normal pair."""
+    import importlib.util
+    import sys
+    name = __name__ + "_frozen_definition"
+    if name in sys.modules:
+        return sys.modules[name]
+    build_frozen_definition()
+    spec = importlib.util.spec_from_file_location(name, os.path.abspath(__file__))
+    m = importlib.util.module_from_spec(spec)
+    sys.modules[name] = m
+    spec.loader.exec_module(m)
+    m._LIB_PATH = _FROZEN_LIB_PATH
+    m.build = build_frozen_definition
+    return m
+
+
 _lib = None
 
 

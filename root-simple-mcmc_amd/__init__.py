@@ -17,3 +17,11 @@ from . import distributed  # noqa: F401
 def build(**kw):
     """Compile the HIP library in-tree (hipcc, gfx950)."""
     return _build_mod.build(**kw)
+
+
+FROZEN_DEFINITION_LIB_PATH = _build_mod.FROZEN_LIB_PATH
+
+
+def build_frozen_definition():
+    """The test library of the frozen-definition golden set (build.py build_frozen_definition); call after build()."""
+    return _build_mod.build_frozen_definition()

@@ -246,6 +246,32 @@ def build(jobs=None, verbose=False, user_likelihood=None, output=None, with_plai
     return result
 
 
+FROZEN_DEFINITION_FLAGS = ["-DSMCMC_PHILOX_ROUNDS=10", "-DSMCMC_NORMAL_TEXTBOOK=1"]
+FROZEN_DEFINITION_UNITS = (("smcmc_inst.hip", ["-DSMCMC_DP=7", "-DSMCMC_LIKE=0"], "inst_dp7_l0"),
+                           ("smcmc_inst.hip", ["-DSMCMC_DP=15", "-DSMCMC_LIKE=0"], "inst_dp15_l0"))
+FROZEN_LIB_PATH = os.path.join(LIB_DIR, "libsmcmc_amd_frozen_definition.so")
+
+
+def build_frozen_definition():
+    """TEST LIBRARY of the frozen-definition golden set (tests/golden/frozen_definition_*.npz, include/smcmc_detmath.h):
+    the plain library with the D <= 15 README-form step kernels recompiled with ten Philox rounds and the textbook normal
+    pair.  Every other kernel in it still draws as the product does -- it serves tests/test_gpu_parity.py's frozen
+    cases (D <= 15, SMCMC_LIKE_ISO_GAUSS, frozen / pooled covariance) and nothing else.  Call after build()."""
+    objs = {u[2]: os.path.join(OBJ_DIR, u[2] + ".o") for u in _units(None)}
+    rebuilt = False
+    for src, defs, name in FROZEN_DEFINITION_UNITS:
+        obj, did = _compile((src, defs + FROZEN_DEFINITION_FLAGS, name + "_frozen_definition"))
+        objs[name] = obj
+        rebuilt = rebuilt or did
+    missing = [o for o in objs.values() if not os.path.exists(o)]
+    if missing:
+        raise RuntimeError("build_frozen_definition: run build() first (missing %s)" % ", ".join(map(os.path.basename, missing)))
+    newest = max(os.path.getmtime(o) for o in objs.values())
+    if rebuilt or not os.path.exists(FROZEN_LIB_PATH) or os.path.getmtime(FROZEN_LIB_PATH) < newest:
+        _link(list(objs.values()), FROZEN_LIB_PATH)
+    return FROZEN_LIB_PATH
+
+
 if __name__ == "__main__":
     import argparse
     ap = argparse.ArgumentParser(description=__doc__)

@@ -94,6 +94,11 @@ __device__ __forceinline__ void normal_tables_ready(NormalTables& a) {
     if constexpr (ASM) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a.le), "+v"(a.ae) : "n"(N));
 }
 __device__ __forceinline__ void normal_pair_lds(uint32_t w0, uint32_t w1, const NormalTables& t, double* n0, double* n1) {
+#ifdef SMCMC_NORMAL_TEXTBOOK
+    (void)t;   // the frozen-definition build (include/smcmc_detmath.h): the textbook pair, no tables
+    smcmc_normal_pair(w0, w1, n0, n1);
+    return;
+#endif
 #define SMCMC_LT_LDS(k, c) (t.le[c])
 #define SMCMC_AT_LDS(c) (t.ae[c])
     SMCMC_NORMAL_PAIR_BODY_HALFCIRCLE(SMCMC_LT_LDS, SMCMC_AT_LDS)

@@ -218,6 +218,28 @@ def round2():
     save_new("hmc_gradient_types_d12.npz", lambda: hmc_ensemble(12, O.LIKE_ROSENBROCK, 64, [(3, 5), (3, 0), (3, 2), (2, 3)], params=[100.0]))
 
 
+def frozen_definition():
+    """The one golden set whose DEFINITION does not move with the engine: the draws are Philox4x32
+    with the paper's ten rounds and the textbook Box-Muller pair through the <= 1 ulp functions of include/smcmc_detmath.h
+    (-DSMCMC_PHILOX_ROUNDS=10 -DSMCMC_NORMAL_TEXTBOOK, honoured by the oracle and by the kernels of
+    lib/libsmcmc_amd_frozen_definition.so).  Written once (round 4); `python tests/golden/make_golden.py
+    --frozen-definition` refuses to overwrite."""
+    global O
+    plain = O
+    O = plain.frozen_definition()
+    try:
+        for name, make in (("frozen_definition_iso_d5.npz", lambda: frozen_chains(5, O.LIKE_ISO, 6, 300, np.zeros(5))),
+                           ("frozen_definition_pooled_iso_d12.npz", lambda: pooled(12, O.LIKE_ISO, 200, 24, 3))):
+            path = os.path.join(HERE, name)
+            if os.path.exists(path):
+                print(name, "exists: left alone")
+                continue
+            np.savez(path, **make())
+            print("wrote", name)
+    finally:
+        O = plain
+
+
 def main():
     O.build()
     if "--round2" in sys.argv:
@@ -244,6 +266,10 @@ def main():
     np.savez(os.path.join(HERE, "hmc_quadform_d60_reference.npz"), **hmc_chains(60, 6, 6, 8, 0.05, 0.3, False))
     np.savez(os.path.join(HERE, "hmc_quadform_d60_fused.npz"), **hmc_chains(60, 6, 6, 8, 0.05, 0.3, True))
 
+
+if __name__ == "__main__" and "--frozen-definition" in sys.argv:
+    frozen_definition()
+    raise SystemExit(0)
 
 if __name__ == "__main__":
     # The fixtures are frozen (MANIFEST.json, tests/test_golden.py::test_the_fixtures_are_the_frozen_ones): a kernel

@@ -18,8 +18,15 @@ def _load(name):
     return {k: v for k, v in np.load(os.path.join(GOLDEN, name)).items()}
 
 
+FROZEN_DEFINITION = {"frozen": "frozen_definition_iso_d5.npz", "pooled": "frozen_definition_pooled_iso_d12.npz"}
+
+
 @pytest.mark.parametrize("name", FROZEN)
 def test_oracle_reproduces_frozen_golden(oracle, name):
+    _oracle_frozen(oracle, name)
+
+
+def _oracle_frozen(oracle, name):
     g = _load(name)
     dim, kind, steps = int(g["dim"]), int(g["kind"]), int(g["steps"])
     for ch in range(g["accepted"].shape[0]):
@@ -36,6 +43,10 @@ def test_oracle_reproduces_frozen_golden(oracle, name):
 
 @pytest.mark.parametrize("name", POOLED)
 def test_oracle_reproduces_pooled_golden(oracle, name):
+    _oracle_pooled(oracle, name)
+
+
+def _oracle_pooled(oracle, name):
     g = _load(name)
     e = oracle.Ensemble(int(g["nchains"]), int(g["dim"]), kind=int(g["kind"]), seed=int(g["seed"]),
                         mode=oracle.MODE_POOLED)
@@ -53,11 +64,15 @@ def test_oracle_reproduces_pooled_golden(oracle, name):
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", FROZEN)
 def test_hip_reproduces_frozen_golden(gpu, name):
+    _hip_frozen(gpu, name)
+
+
+def _hip_frozen(gpu, name, library=None):
     g = _load(name)
     dim, kind, steps = int(g["dim"]), int(g["kind"]), int(g["steps"])
     nch = g["accepted"].shape[0]
     prm = [100.0] if kind == 2 else None
-    e = gpu.Engine(dim, nch, likelihood=kind, likelihood_params=prm, seed=int(g["seed"]), mode=gpu.MODE_FROZEN)
+    e = gpu.Engine(dim, nch, likelihood=kind, likelihood_params=prm, seed=int(g["seed"]), mode=gpu.MODE_FROZEN, library=library)
     assert e.Start(g["x0"])
     acc, logl, sigma = [], [], []
     for _ in range(steps):
@@ -72,9 +87,13 @@ def test_hip_reproduces_frozen_golden(gpu, name):
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", POOLED)
 def test_hip_reproduces_pooled_golden(gpu, name):
+    _hip_pooled(gpu, name)
+
+
+def _hip_pooled(gpu, name, library=None):
     g = _load(name)
     dim = int(g["dim"])
-    e = gpu.Engine(dim, int(g["nchains"]), likelihood=int(g["kind"]), seed=int(g["seed"]), mode=gpu.MODE_POOLED)
+    e = gpu.Engine(dim, int(g["nchains"]), likelihood=int(g["kind"]), seed=int(g["seed"]), mode=gpu.MODE_POOLED, library=library)
     assert e.Start(np.zeros(dim))
     m = None
     for _ in range(int(g["nwin"])):
@@ -89,6 +108,50 @@ def test_hip_reproduces_pooled_golden(gpu, name):
     assert np.array_equal(e.lane("naccept"), g["naccept"])
     assert np.array_equal(e.decomposition, g["decomposition"]) and np.array_equal(e.covariance, g["covariance"])
     assert np.array_equal(e.GetEstimatedCenter(), g["center"])
+
+
+# ---------------------------------------------------------------- the frozen-definition set
+# One golden set whose definition does not move with the engine: Philox4x32 with the paper's ten rounds and the textbook
+# normal pair (include/smcmc_detmath.h behind -DSMCMC_PHILOX_ROUNDS=10 -DSMCMC_NORMAL_TEXTBOOK), honoured by a second build
+# of the oracle and by lib/libsmcmc_amd_frozen_definition.so (the D <= 15 README-form step kernels recompiled).  Whatever
+# the production draws become, these two files and these tests stay.
+def test_frozen_definition_oracle_reproduces_its_golden(oracle):
+    F = oracle.frozen_definition()
+    assert F.philox_draw_rounds() == 10 and oracle.philox_draw_rounds() == 7
+    _oracle_frozen(F, FROZEN_DEFINITION["frozen"])
+    _oracle_pooled(F, FROZEN_DEFINITION["pooled"])
+    # ... and it is another definition than the production one: the same chain under the two builds
+    g = _load(FROZEN_DEFINITION["frozen"])
+    c = oracle.Chain(int(g["dim"]), kind=int(g["kind"]), seed=int(g["seed"]), chain_id=0)
+    c.set_covariance_frozen(1)
+    assert c.start(g["x0"])
+    c.run(int(g["steps"]))
+    assert not np.array_equal(c.accepted, g["x"][:, 0])
+
+
+def test_frozen_definition_normal_pair_is_the_textbook_formula(oracle):
+    """r = sqrt(-2 ln u1), theta = 2 pi u2 with u = (w + 1/2) 2^-32: the frozen build's pair against numpy's libm to a few
+    ulp, and against the production transform (another function of the same two words, equal to ~1e-15)."""
+    F = oracle.frozen_definition()
+    rng = np.random.default_rng(5)
+    w0 = rng.integers(0, 2 ** 32, 4000, dtype=np.uint64).astype(np.uint32)
+    w1 = rng.integers(0, 2 ** 32, 4000, dtype=np.uint64).astype(np.uint32)
+    n0, n1 = F.det_normal_pair(w0, w1)
+    u1 = (w0.astype(np.float64) + 0.5) * 2.0 ** -32
+    th = 2.0 * np.pi * (w1.astype(np.float64) + 0.5) * 2.0 ** -32
+    r = np.sqrt(-2.0 * np.log(u1))
+    assert np.max(np.abs(n0 - r * np.cos(th))) < 2e-15 * 7 and np.max(np.abs(n1 - r * np.sin(th))) < 2e-15 * 7
+    p0, p1 = oracle.det_normal_pair(w0, w1)
+    assert np.max(np.abs(n0 - p0)) < 1e-14 and np.max(np.abs(n1 - p1)) < 1e-14
+    assert not (np.array_equal(n0, p0) and np.array_equal(n1, p1))
+
+
+@pytest.mark.gpu
+def test_hip_frozen_definition_build_reproduces_its_golden(gpu):
+    lib = gpu.FROZEN_DEFINITION_LIB_PATH
+    assert os.path.exists(lib), "lib/libsmcmc_amd_frozen_definition.so is missing: __graft_entry__.build() makes it"
+    _hip_frozen(gpu, FROZEN_DEFINITION["frozen"], library=lib)
+    _hip_pooled(gpu, FROZEN_DEFINITION["pooled"], library=lib)
 
 
 # ---------------------------------------------------------------- large dimensions and HMC

@@ -28,6 +28,15 @@ def test_library_exports_every_declared_symbol(smcmc):
         assert hasattr(lib, name), f"{name} is declared in include/smcmc.h but not exported"
 
 
+def test_the_frozen_definition_test_library_is_built_and_whole(smcmc):
+    """lib/libsmcmc_amd_frozen_definition.so (build.py build_frozen_definition; tests/test_golden.py's GPU case runs on it)
+    carries the same C ABI as the product library."""
+    assert os.path.exists(smcmc.FROZEN_DEFINITION_LIB_PATH), "__graft_entry__.build() makes it"
+    lib = ctypes.CDLL(smcmc.FROZEN_DEFINITION_LIB_PATH)
+    for name in _declared_symbols():
+        assert hasattr(lib, name), name
+
+
 def test_build_facts_without_a_gpu(smcmc):
     lib = smcmc.load()
     assert lib.smcmc_version() >= 100

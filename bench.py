@@ -138,11 +138,12 @@ def extra_metropolis(pkg, torch, stream, name, dim, chains, like, like_id, prm, 
     quadform_walk = None
     if like_id == pkg.LIKE_QUADFORM:
         quadform_walk = "dense D^2-term sum" if eng.get_param("DENSE_QUADFORM") else "non-zero entries of Error only (bit for bit the dense sum)"
+    gc.collect(); gc.disable()                        # a full collection of a torch-sized heap stalls the host for ~70 ms: here,
+                                                      # not next to the timed windows (an idle GPU drops its clocks)
     for _ in range(adapt_windows):                    # adaptation windows before the timed ones (the proposal has settled)
         eng.Step(window); eng.sync()
     torch.cuda.synchronize()
     acc0, steps0 = float(eng.lane("naccept").sum()), eng.get_param("TOTAL_STEPS")
-    gc.collect(); gc.disable()                        # a full collection of a torch-sized heap stalls the host for ~70 ms
     evs = []
     t0 = time.perf_counter()
     for _ in range(windows):
@@ -237,10 +238,10 @@ def extra_hmc(pkg, torch, stream, dim, chains, leapfrog, exact, steps, tuned, bu
     elif eps0 is not None:
         h.SetMeanEpsilon(eps0)
     h.SetLeapFrog(leapfrog)
+    gc.collect(); gc.disable()
     h.Step(burn)
     torch.cuda.synchronize()
     acc0, tr0 = h.lane("naccept").astype(np.float64).sum(), h.lane("trials").astype(np.float64).sum()
-    gc.collect(); gc.disable()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     e0.record(stream)
@@ -323,10 +324,10 @@ def bench_c5(args, pkg, torch, dist, rank, world, local, stream, leapfrog=20):
             dist.barrier()
         torch.cuda.synchronize()
 
+    gc.collect(); gc.disable()    # (before the warm-up: see main())
     pkg.distributed.run_windows(backend, args.warmup, args.window)
     backend.events.clear(); backend.comm_events.clear()
     acc0, tr0 = h.lane("naccept").astype(np.float64).sum(), h.lane("trials").astype(np.float64).sum()
-    gc.collect(); gc.disable()
     fence()
     t0 = time.perf_counter()
     pkg.distributed.run_windows(backend, args.steps, args.window)
@@ -476,10 +477,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # The collector runs BEFORE the warm-up windows, not between them and the timed region: a full collection of a
+    # torch-sized heap takes tens of milliseconds, the idle GPU drops its clocks, and the first timed windows then run
+    # 2 - 3 % slow until they are back (20 timed windows: 3.91e9 with the pause there, 60 windows 4.03e9 either way).
+    gc.collect(); gc.disable()    # ... and no collector pauses inside the timed region
     pkg.distributed.run_windows(backend, args.warmup, args.window)
     backend.events.clear()
     backend.comm_events.clear()
-    gc.collect(); gc.disable()    # no collector pauses inside the timed region
     fence()
     t0 = time.perf_counter()
     pkg.distributed.run_windows(backend, args.steps, args.window)

@@ -180,10 +180,11 @@ template <int NE>
 constexpr int kPwMaxDim = NE == 4 ? 22 : NE == 12 ? 38 : NE == 20 ? 50 : 63;
 
 // grid = nchains workgroups of one wavefront.  NE: registers of packed covariance per lane (perchain_wave_elements).
-template <int LIKE, int NE>
-// (NE = 4, D <= 22: held to 256 registers -- a dozen scratch accesses -- so that two wavefronts share a SIMD: + 11 - 17 %
-// from 16 384 chains on.  The larger classes pay 5 x for that: 336 - 1 179 scratch accesses.)
-__attribute__((amdgpu_waves_per_eu(NE == 4 ? 2 : 1)))
+// PAIRED (NE = 4, D <= 22, ensembles of more wavefronts than the chip has SIMDs): held to 256 registers so that two
+// wavefronts share a SIMD: + 11 - 17 % from 16 384 chains on, and 4 % slower for a single chain (hence the switch).  The
+// larger classes pay 3 - 5 x for that (336 - 1 179 scratch accesses): never paired.
+template <int LIKE, int NE, bool PAIRED = false>
+__attribute__((amdgpu_waves_per_eu(PAIRED ? 2 : 1)))
 __global__ void __launch_bounds__(kWave) perchain_wave_kernel(const PerChainParams p, const PerChainRecord rec) {
     constexpr int DMAX = kPwMaxDim<NE>;
     __shared__ double ul[2048];          // UpdateProposal's workspace: the decomposition, column packed (U(i, j), i <= j, at j (j + 1) / 2 + i)

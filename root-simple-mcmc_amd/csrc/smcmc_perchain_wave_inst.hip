@@ -4,16 +4,16 @@
 
 namespace smcmc {
 
-template <int LIKE, int NE>
+template <int LIKE, int NE, bool PAIRED = false>
 static hipError_t go_wave(const PerChainParams& p, const PerChainRecord& rec, hipStream_t s) {
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(perchain_wave_kernel<LIKE, NE>), dim3(p.nchains), dim3(kWave), 0, s, p, rec);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(perchain_wave_kernel<LIKE, NE, PAIRED>), dim3(p.nchains), dim3(kWave), 0, s, p, rec);
     return hipGetLastError();
 }
 
 template <int LIKE>
 static hipError_t go_wave_like(const PerChainParams& p, const PerChainRecord& rec, hipStream_t s) {
     switch (perchain_wave_elements(p.dim)) {
-        case 4: return go_wave<LIKE, 4>(p, rec, s);
+        case 4: return (p.nchains > 1024) ? go_wave<LIKE, 4, true>(p, rec, s) : go_wave<LIKE, 4>(p, rec, s);   // 1 024 SIMDs
         case 12: return go_wave<LIKE, 12>(p, rec, s);
         case 20: return go_wave<LIKE, 20>(p, rec, s);
         default: return go_wave<LIKE, 32>(p, rec, s);

@@ -29,5 +29,7 @@ $R/root-simple-mcmc_amd/build/micro/lds_bcast > $O/lds_bcast.txt 2>&1
 python3 $R/tools/micro/pwprof.py 2>&1 | grep "cycles per step" > $O/perchain_wave_sections.txt
 python3 $R/tools/record_cost.py 2>&1 | grep "us per step" > $O/record_cost.txt
 python3 $R/tools/step_loop_time.py 2>&1 | grep steps_per_s > $O/step_loop.txt
-python3 $R/bench.py > $O/bench.json 2> $O/bench.err
+# the flags the round's driver uses, on their own (short timed region)
+python3 $R/bench.py --steps 20 --warmup 5 --no-extras --no-ess --no-cpu-baseline > $O/bench_driver_flags.json 2>> $O/bench.err
+python3 $R/bench.py > $O/bench.json 2>> $O/bench.err
 tail -1 $O/bench.json | cut -c1-300

@@ -43,10 +43,17 @@ int main(int argc, char** argv) {
         mcmc.GetProposeStep().SetDim(like.GetDim());
         sMCMC::Vector p(like.GetDim(), 0.5);
         if (!mcmc.Start(p, true)) return 1;
-        for (int w = 0; w < 20; ++w) {
-            mcmc.StepMany(200);
-            mcmc.GetProposeStep().SyncPooledCovariance();
-            mcmc.SaveStep(false);
+        if (chains == 1) {
+            // the reference's own use: one chain adapting alone, Step() one call at a time (served from recorded launches
+            // of the one-chain-per-wavefront kernel, which evaluates the user's function on the whole point)
+            for (int i = 0; i < 4000; ++i) mcmc.Step(i % 100 == 0);
+            std::cout << "Step() runs ahead: " << (mcmc.GetRunAhead() ? 1 : 0) << std::endl;
+        } else {
+            for (int w = 0; w < 20; ++w) {
+                mcmc.StepMany(200);
+                mcmc.GetProposeStep().SyncPooledCovariance();
+                mcmc.SaveStep(false);
+            }
         }
         // the device's likelihood of chain 0's point against the host functor
         const double host = like(mcmc.GetAccepted());

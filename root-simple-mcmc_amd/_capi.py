@@ -189,6 +189,14 @@ class SmcmcError(RuntimeError):
 
 
 def _bind(path):
+    # One HIP runtime per process: PyTorch-ROCm carries its own libamdhip64 and the library is linked against /opt/rocm's
+    # (same SONAME).  Whichever is loaded first serves both -- but if this library came first and torch then initialised
+    # its own copy, the process would hold two runtimes and the second sees no device ("no HIP device").  So torch, when
+    # it is installed, is imported before the library is opened.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)   # AttributeError if the library lacks a declared symbol

@@ -49,11 +49,13 @@ def _units(user_flag=None):
     engine = ("smcmc_engine.hip", [user_flag], "engine_user") if user_flag else ("smcmc_engine.hip", [], "engine")
     vaat = ("smcmc_vaat_engine.hip", [user_flag], "vaat_engine_user") if user_flag else ("smcmc_vaat_engine.hip", [], "vaat_engine")
     hmc = ("smcmc_hmc_engine.hip", [user_flag], "hmc_engine_user") if user_flag else ("smcmc_hmc_engine.hip", [], "hmc_engine")
+    wave = (("smcmc_perchain_wave_inst.hip", [user_flag], "perchain_wave_user") if user_flag
+            else ("smcmc_perchain_wave_inst.hip", [], "perchain_wave"))
     units = [engine, ("smcmc_selftest.hip", [], "selftest"), ("smcmc_autocorr.hip", [], "autocorr"),
              hmc, ("smcmc_hmc_mfma_inst.hip", [], "hmc_mfma"),
              vaat, ("smcmc_vaat_large.hip", [], "vaat_large"),
              ("smcmc_pooled_update.hip", [], "pooled_update"), ("smcmc_perchain_inst.hip", [], "perchain"),
-             ("smcmc_perchain_wave_inst.hip", [], "perchain_wave"),
+             wave,
              ("smcmc_panel_mfma_inst.hip", [], "panel_mfma"), ("smcmc_fold_inst.hip", [], "fold")]
     for dp in dp_list():
         for like in LIKELIHOODS:

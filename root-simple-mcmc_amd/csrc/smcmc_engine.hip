@@ -905,6 +905,7 @@ PerChainParams pc_params(smcmc_engine* h, const StepParams& p) {
 // lane; the two kernels share every image, so the choice can change from launch to launch.
 bool pc_use_wave(const smcmc_engine* h) {
     if (!smcmc::perchain_wave_serves(h->likelihood)) return false;
+    if (h->likelihood == SMCMC_LIKE_USER) return true;     // (the one-chain-per-lane kernel has no user instantiation)
     if (h->pc_wave >= 0) return h->pc_wave != 0;
     return true;     // measured faster at every ensemble size, 1 to 65 536 chains (profiles/r04_notes.md)
 }
@@ -935,7 +936,7 @@ int pc_check_supported(smcmc_engine* h) {
         return fail(h, SMCMC_ERR_UNSUPPORTED, "SMCMC_MODE_PER_CHAIN serves dim <= 63");
     if (!h->exact)
         return fail(h, SMCMC_ERR_UNSUPPORTED, "SMCMC_MODE_PER_CHAIN runs in reference-order arithmetic (SMCMC_P_EXACT_ARITHMETIC = 1)");
-    if (h->likelihood == SMCMC_LIKE_USER)
+    if (h->likelihood == SMCMC_LIKE_USER && !smcmc::perchain_wave_serves(SMCMC_LIKE_USER))   // (the one-chain-per-wavefront kernel only)
         return fail(h, SMCMC_ERR_UNSUPPORTED, "SMCMC_MODE_PER_CHAIN serves the built-in likelihoods");
     for (int d = 0; d < h->dim; ++d)
         if (h->prop->ptype[d] != 0)

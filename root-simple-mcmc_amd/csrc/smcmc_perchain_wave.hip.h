@@ -160,6 +160,15 @@ __device__ __forceinline__ double pw_loglike(const double* p, double pi, int D, 
         double v = pi - like[2 + il];
         v /= like[2 + D + il];
         lsum = pw_ordered_sum<DMAX>(-(0.5 * v * v), D, scratch, lsum);     // x - t and x + (-t) are the same rounding
+#ifdef SMCMC_USER_LIKELIHOOD
+    } else if constexpr (LIKE == SMCMC_LIKE_USER) {
+        // the user's function of the whole point (smcmc_user_loglike<DP>, smcmc_kernels.hip.h): every lane takes the point
+        // from LDS (p, zero past D) into a register array and evaluates it -- 64 times the same value, one evaluation's time
+        constexpr int DPU = (DMAX + 1) / 2 * 2;
+        double v[DPU];
+        pw_fetch_all<DMAX>(p, v);
+        lsum = smcmc_user_loglike<DPU>(v, as_const(like), D);
+#endif
     } else {
         static_assert(LIKE == SMCMC_LIKE_ROSENBROCK, "the likelihoods the wave kernel serves");
         // THardLogLikelihood.H:57-67: logL -= a a + 100 b b with a = 1 - p[i], b = p[i + 1] - p[i]^2, i ascending:
@@ -191,7 +200,7 @@ __global__ void __launch_bounds__(kWave) perchain_wave_kernel(const PerChainPara
     __shared__ __attribute__((aligned(16))) double dv[kWave];   // x - c of UpdateState; the diagonal of the covariance while a trace is summed
     __shared__ __attribute__((aligned(16))) double zv[kWave];   // sigma r_i of the step, for every lane to read
     __shared__ __attribute__((aligned(16))) double sv[kWave];   // the terms of an ordered sum
-    __shared__ double ps[kWave];         // QUADFORM: the proposal, for the walk over the entries of Error
+    __shared__ __attribute__((aligned(16))) double ps[kWave];   // QUADFORM / USER: the proposal where every lane can read all of it
     // One step's record (PerChainRecord) is put together here and leaves in three coalesced stores; behind it one slot
     // per lane for the writes of the elements that are not on the diagonal (so that no write needs a predicate).
     constexpr int kRecDump = 3 * kWave + 16;
@@ -517,9 +526,9 @@ __global__ void __launch_bounds__(kWave) perchain_wave_kernel(const PerChainPara
                 step_rms = __builtin_sqrt(ms);
             }
             PW_MARK(6)
-            if constexpr (LIKE == SMCMC_LIKE_QUADFORM) {
+            if constexpr (LIKE == SMCMC_LIKE_QUADFORM || LIKE == SMCMC_LIKE_USER) {
                 __syncthreads();
-                ps[lane] = xpi;
+                ps[lane] = mine ? xpi : 0.0;
                 __syncthreads();
             }
             logl_prop = pw_loglike<LIKE, DMAX>(ps, xpi, D, p.like, p.like_csr, sv);
@@ -621,6 +630,9 @@ __global__ void __launch_bounds__(kWave) perchain_wave_kernel(const PerChainPara
 
 // the likelihoods the wave kernel serves
 inline bool perchain_wave_serves(int like) {
+#ifdef SMCMC_USER_LIKELIHOOD
+    if (like == SMCMC_LIKE_USER) return true;      // (a library built with a user likelihood: build.py --user-likelihood)
+#endif
     return like == SMCMC_LIKE_ISO_GAUSS || like == SMCMC_LIKE_QUADFORM || like == SMCMC_LIKE_ROSENBROCK ||
            like == SMCMC_LIKE_ASYM || like == SMCMC_LIKE_HORRIFIC || like == SMCMC_LIKE_CONSTRAINED;
 }

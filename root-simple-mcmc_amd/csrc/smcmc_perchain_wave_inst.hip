@@ -35,6 +35,9 @@ hipError_t launch_perchain_wave(const PerChainParams& p, const PerChainRecord& r
         case SMCMC_LIKE_ASYM: return go_wave_like<SMCMC_LIKE_ASYM>(p, rec, s);
         case SMCMC_LIKE_HORRIFIC: return go_wave_like<SMCMC_LIKE_HORRIFIC>(p, rec, s);
         case SMCMC_LIKE_CONSTRAINED: return go_wave_like<SMCMC_LIKE_CONSTRAINED>(p, rec, s);
+#ifdef SMCMC_USER_LIKELIHOOD
+        case SMCMC_LIKE_USER: return go_wave_like<SMCMC_LIKE_USER>(p, rec, s);
+#endif
         default: return hipErrorInvalidValue;
     }
 }

@@ -59,6 +59,35 @@ def test_asymmetric_user_likelihood_runs_in_the_step_kernel(gpu, mode):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dim,n", [(10, 6), (30, 3), (50, 2), (63, 2)])
+def test_user_likelihood_with_every_chain_adapting_alone(gpu, oracle, dim, n):
+    """SMCMC_MODE_PER_CHAIN with a user likelihood (the reference's own mode for a user's functor): the one-chain-per-
+    wavefront kernel evaluates smcmc_user_loglike on the whole point in every lane; the example is TASymLogLikelihood, so
+    every chain is oracle.Chain with that likelihood, bit for bit, through its own UpdateProposal events; and the
+    per-step record (what TSimpleMCMC_amd.H::Step() runs ahead on) is the chain step by step."""
+    slopes = np.array([-1.0, 100.0])
+    e = gpu.Engine(dim, n, likelihood=gpu.LIKE_USER, likelihood_params=slopes, library=_user_lib(gpu),
+                   mode=gpu.MODE_PER_CHAIN, seed=11)
+    assert e.get_param("PERCHAIN_WAVE") == 1.0
+    chains = [oracle.Chain(dim, kind=oracle.LIKE_ASYM, seed=11, chain_id=c) for c in range(n)]
+    x0 = np.full(dim, 0.5)
+    assert e.Start(x0)
+    for c in chains:
+        assert c.start(x0)
+    for steps in (700, 1500):
+        e.Step(steps)
+        for c in chains:
+            c.run_quiet(steps)
+        x, logl, sigma = e.GetAccepted(), e.GetAcceptedLogLikelihood(), e.lane("sigma")
+        for k, c in enumerate(chains):
+            assert np.array_equal(x[:, k], c.accepted) and logl[k] == c.scalars["accepted_logl"] and sigma[k] == c.scalars["sigma"]
+    rec = e.StepRecorded(40)
+    for k in range(40):
+        chains[0].step(False, 0)
+        assert np.array_equal(rec["accepted"][k], chains[0].accepted)
+
+
+@pytest.mark.gpu
 def test_user_likelihood_limits(gpu):
     with pytest.raises(gpu.SmcmcError) as err:
         gpu.Engine(600, 64, likelihood=gpu.LIKE_USER, library=_user_lib(gpu))      # dim <= 512
@@ -138,6 +167,11 @@ def test_cpp_host_with_a_user_likelihood(gpu, tmp_path):
     r = subprocess.run([exe, "512"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "(identical)" in r.stdout
+    # ... and as the reference is used: ONE chain adapting alone, Step() per call (SMCMC_MODE_PER_CHAIN with the user's
+    # function in the one-chain-per-wavefront kernel, Step() running ahead on its record)
+    r = subprocess.run([exe, "1"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "(identical)" in r.stdout and "Step() runs ahead: 1" in r.stdout
 
 
 @pytest.mark.gpu

@@ -195,7 +195,7 @@ def _bind(path):
     # it is installed, is imported before the library is opened.
     try:
         import torch  # noqa: F401
-    except ImportError:
+    except Exception:   # not installed, or unusable: the library stands on /opt/rocm's runtime alone
         pass
     lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():

@@ -980,10 +980,14 @@ __device__ __forceinline__ size_t packed_to_tile_offset(int k, int D) {
     return ((size_t)(ti * (ti + 1) / 2 + tj) * 4 + reg) * kWave + lane;
 }
 
-// level 1: thread (k, chunk) -> chunk_sums[chunk][k]
+// level 1: thread (k, chunk) -> chunk_sums[chunk][k]; it leaves ZERO in the accumulator entries it read (the next window
+// accumulates into them -- rounds 1-3 cleared all 21 MB of accumulators with a memset per window; entries nobody reads,
+// the lower halves of the diagonal tiles, keep growing unread).
+// (Both levels in one launch -- the last workgroup of a range of k adding the chunk sums -- was built and measured:
+// 36 us instead of 14.  Workgroups on different XCDs only see each other's stores after an agent-scope release, which
+// on this chip writes the XCD's L2 back, once per workgroup.)
 template <int DP>
-__global__ void reduce_chunks_kernel(const double* __restrict__ gacc, int ngroups, int D,
-                                     double* __restrict__ chunk_sums) {
+__global__ void reduce_chunks_kernel(double* __restrict__ gacc, int ngroups, int D, double* __restrict__ chunk_sums) {
     constexpr int NT = Geo<DP>::NT;
     const int npk = (D + 1) * (D + 2) / 2;
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -996,6 +1000,9 @@ __global__ void reduce_chunks_kernel(const double* __restrict__ gacc, int ngroup
     double v[kReduceChunk];
 #pragma unroll
     for (int q = 0; q < kReduceChunk; ++q) v[q] = (g0 + q < g1) ? gacc[(size_t)(g0 + q) * gstride + off] : 0.0;
+#pragma unroll
+    for (int q = 0; q < kReduceChunk; ++q)
+        if (g0 + q < g1) gacc[(size_t)(g0 + q) * gstride + off] = 0.0;
     double s = 0.0;
 #pragma unroll
     for (int q = 0; q < kReduceChunk; ++q)
@@ -1009,8 +1016,17 @@ __global__ void reduce_final_kernel(const double* __restrict__ chunk_sums, int n
                                     double* __restrict__ moments) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= npk) return;
+    // (the loads go out in batches of 16 -- one at a time this launch was 9 us of load latency --, the additions stay in
+    // chunk order)
     double s = 0.0;
-    for (int c = 0; c < nchunks; ++c) s += chunk_sums[(size_t)c * npk + k];
+    for (int c0 = 0; c0 < nchunks; c0 += 16) {
+        double v[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = (c0 + q < nchunks) ? chunk_sums[(size_t)(c0 + q) * npk + k] : 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+            if (c0 + q < nchunks) s += v[q];
+    }
     moments[k] = s;
 }
 

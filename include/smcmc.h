@@ -118,10 +118,10 @@ typedef enum {
     SMCMC_P_PERCHAIN_WAVE = 25,         /* SMCMC_MODE_PER_CHAIN: which kernel steps the chains.  1: one chain per WAVEFRONT (the chain's
                                          * covariance in registers, its decomposition in LDS for a whole launch: the kernel for few
                                          * chains, down to the single chain of SimpleMCMC.C); 0: one chain per lane (its O(D^2) state
-                                         * streamed through HBM every step); -1 (default): per wavefront wherever the likelihood
-                                         * is one it serves.  Same images, same bits either way; the likelihoods of
-                                         * the stress tests (ASYM, HORRIFIC, CONSTRAINED) always run one chain per lane.  Reads back
-                                         * what runs. */
+                                         * streamed through HBM every step); -1 (default): per wavefront.  Same images, same
+                                         * bits either way.  Every built-in likelihood runs on both; SMCMC_LIKE_USER (a library
+                                         * built with a user likelihood) on the per-wavefront kernel only, whatever is set
+                                         * here.  Reads back what runs. */
     SMCMC_P_COUNT_
 } smcmc_param;
 

@@ -279,40 +279,44 @@ __global__ void __launch_bounds__(512) pooled_small_update_kernel(const PooledUp
         if (tid == 0) p.scal[kPsStatus] = s_state;
         return;
     }
-    // ---- SharedProposal::cholesky: row c of U from the rows above it, one lane per column ----
-    // ONE wavefront does it (D <= 64 columns): no workgroup barrier between the rows, only the order of its own LDS
-    // operations (a wavefront's LDS instructions execute in issue order), and the operands of a row's subtractions are
-    // read sixteen ahead of the chain of subtractions.  Same subtractions in the same order: v -= U(rr, j) U(rr, c), rr
-    // ascending, un-fused.
-    if (tid < 64) {
-        const int jj = tid, jc = jj < D ? jj : 0;
-        int state = kPooledOk;
-        for (int c = 0; c < D && state == kPooledOk; ++c) {
-            double v = R[c][jc];
-            int r0 = 0;
-            for (; r0 + 16 <= c; r0 += 16) {
-                double a[16], bq[16];
-#pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    a[u] = R[r0 + u][jc];
-                    bq[u] = R[r0 + u][c];
-                }
-#pragma unroll
-                for (int u = 0; u < 16; ++u) v -= a[u] * bq[u];
-            }
-            for (; r0 < c; ++r0) v -= R[r0][jc] * R[r0][c];
-            const double piv = __shfl(v, c);
+    // ---- SharedProposal::cholesky ----
+    // Row by row as the reference's decomposition goes, but RIGHT-LOOKING: once row c is final, every element (i, j),
+    // c < i <= j, of the rows below takes ITS subtraction of that row at once -- v -= U(c, i) U(c, j), un-fused -- spread
+    // over all 512 threads; by the time row i is the pivot row its elements have seen r = 0 .. i - 1 in ascending order,
+    // the same subtractions in the same order as a dot product over the rows above (a product's operands swapped:
+    // commutative).  Two workgroup barriers per row instead of a chain of c dependent LDS round trips: the one-wavefront
+    // left-looking version was 38 of this kernel's 44 us at D = 50.
+    // tab: the elements (i, j), i <= j, with the rows in DESCENDING order, so that the block below row c is the first
+    // (D - 1 - c)(D - c) / 2 entries.
+    __shared__ unsigned short tab[kSmallDim * (kSmallDim + 1) / 2];
+    for (int e = tid; e < D * (D + 1) / 2; e += 512) {
+        int m = (int)((__builtin_sqrt(8.0 * (double)e + 1.0) - 1.0) * 0.5);   // rows below the top: m (m + 1) / 2 <= e
+        while ((m + 1) * (m + 2) / 2 <= e) ++m;
+        while (m * (m + 1) / 2 > e) --m;
+        const int i = D - 1 - m;
+        tab[e] = (unsigned short)((i << 8) | (i + (e - m * (m + 1) / 2)));
+    }
+    for (int c = 0; c < D; ++c) {
+        __syncthreads();                       // the subtractions of row c - 1 are in (and tab, the first time)
+        if (tid < 64) {
+            const double piv = R[c][c];
             if (!(piv > 0.0) || !__builtin_isfinite(piv)) {
-                state = kPooledCholeskyFailed;
+                if (tid == 0) s_state = kPooledCholeskyFailed;
             } else {
                 const double root = __builtin_sqrt(piv);
-                if (jj == c) R[c][c] = root;
-                else if (jj > c && jj < D) R[c][jj] = v / root;
+                if (tid == c) R[c][c] = root;
+                else if (tid > c && tid < D) R[c][tid] = R[c][tid] / root;
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the row is in LDS before the next row reads it
-            __builtin_amdgcn_wave_barrier();
         }
-        if (tid == 0) s_state = state;
+        __syncthreads();                       // row c is final
+        if (s_state != kPooledOk) break;       // (uniform: read behind the barrier)
+        const int below = (D - 1 - c) * (D - c) / 2;
+        for (int e = tid; e < below; e += 512) {
+            const int ij = tab[e], i = ij >> 8, j = ij & 255;
+            double v = R[i][j];
+            v -= R[c][i] * R[c][j];
+            R[i][j] = v;
+        }
     }
     __syncthreads();
     if (s_state != kPooledOk) {

@@ -128,6 +128,7 @@ struct smcmc_engine {
     bool overlap_update = false;   // SMCMC_P_OVERLAP_UPDATE
     double *d_centre = nullptr, *d_cov = nullptr, *d_decomp = nullptr, *d_scal = nullptr;
     double* h_scal = nullptr;      // pinned: the scalars (status word included) of the latest device update
+    double* h_scal_dev = nullptr;  // ... as the device addresses it (hipHostGetDevicePointer), null if it cannot
     hipEvent_t status_event = nullptr;
     bool update_prepared = false;  // pooled_update_prepare() has run on this engine's device
     bool status_pending = false;   // a device update whose status the host has not looked at yet
@@ -648,10 +649,12 @@ int device_apply(smcmc_engine* h) {
     }
     P.lastPath = 0;
     P.decompFull = false;
+    // (the kernel also writes the update's scalars into h_scal, pinned and device-visible: no copy command behind it)
     e = launch_pooled_adjust_lanes(h->d_lane_f64, h->npad, h->nchains, h->d_scal, acc_w, acc_wW, SMCMC_LANE_SIGMA,
-                                   SMCMC_LANE_ACCEPTANCE_TRIALS, h->stream);
+                                   SMCMC_LANE_ACCEPTANCE_TRIALS, h->h_scal_dev, h->stream);
     if (e != hipSuccess) return fail(h, SMCMC_ERR_HIP, std::string("adjust_lanes launch: ") + hipGetErrorString(e));
-    HIP_TRY(h, hipMemcpyAsync(h->h_scal, h->d_scal, sizeof(double) * kPsCount, hipMemcpyDeviceToHost, h->stream));
+    if (!h->h_scal_dev)
+        HIP_TRY(h, hipMemcpyAsync(h->h_scal, h->d_scal, sizeof(double) * kPsCount, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipEventRecord(h->status_event, h->stream));
     h->status_pending = true;
     h->host_stale = true;
@@ -1266,6 +1269,10 @@ int smcmc_create(int dim, int nchains, int likelihood, uint64_t seed, uint32_t c
     HIP_TRY(h, hipMalloc(&h->d_scal, sizeof(double) * kPsCount));
     HIP_TRY(h, hipMemset(h->d_scal, 0, sizeof(double) * kPsCount));
     HIP_TRY(h, hipHostMalloc((void**)&h->h_scal, sizeof(double) * kPsCount, hipHostMallocDefault));
+    if (hipHostGetDevicePointer((void**)&h->h_scal_dev, h->h_scal, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        h->h_scal_dev = nullptr;
+    }
     HIP_TRY(h, hipEventCreateWithFlags(&h->status_event, hipEventDisableTiming));
     return SMCMC_OK;
 }

@@ -189,7 +189,11 @@ __global__ void __launch_bounds__(256) pooled_publish_kernel(const PooledPublish
 }
 
 __global__ void __launch_bounds__(256) pooled_adjust_lanes_kernel(double* lane_f64, int npad, int nchains, const double* scal,
-                                                                   double acc_w, double acc_wW, int sigma_lane, int trials_lane) {
+                                                                   double acc_w, double acc_wW, int sigma_lane, int trials_lane,
+                                                                   double* host_scal) {
+    // the update's scalars (status word included) for the host: written straight into its pinned, device-visible copy --
+    // there when the launch has completed -- instead of a copy command behind this kernel
+    if (host_scal != nullptr && blockIdx.x == 0 && threadIdx.x < kPsCount) host_scal[threadIdx.x] = scal[threadIdx.x];
     if (scal[kPsStatus] != kPooledOk) return;
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= nchains) return;
@@ -379,9 +383,10 @@ hipError_t launch_pooled_publish(const PooledPublishParams& p, hipStream_t s) {
 }
 
 hipError_t launch_pooled_adjust_lanes(double* lane_f64, int npad, int nchains, const double* scal, double acc_w, double acc_wW,
-                                      int sigma_lane, int trials_lane, hipStream_t s) {
+                                      int sigma_lane, int trials_lane, double* host_scal, hipStream_t s) {
+    static_assert(kPsCount <= 256, "one thread per scalar");
     hipLaunchKernelGGL(pooled_adjust_lanes_kernel, dim3((nchains + 255) / 256), dim3(256), 0, s, lane_f64, npad, nchains, scal,
-                       acc_w, acc_wW, sigma_lane, trials_lane);
+                       acc_w, acc_wW, sigma_lane, trials_lane, host_scal);
     return hipGetLastError();
 }
 

@@ -63,8 +63,9 @@ hipError_t launch_pooled_update(const PooledUpdateParams& p, hipStream_t stream)
 hipError_t launch_pooled_publish(const PooledPublishParams& p, hipStream_t stream);
 // dim <= 64 with the register kernels' layout of U (q.DP > 0): update and publish in one single-workgroup kernel
 hipError_t launch_pooled_small_update(const PooledUpdateParams& p, const PooledPublishParams& q, hipStream_t stream);
+// host_scal: the pinned host copy of the kPsCount scalars as the device sees it (or null: the caller copies them itself)
 hipError_t launch_pooled_adjust_lanes(double* lane_f64, int npad, int nchains, const double* scal, double acc_w,
-                                      double acc_wW, int sigma_lane, int trials_lane, hipStream_t stream);
+                                      double acc_wW, int sigma_lane, int trials_lane, double* host_scal, hipStream_t stream);
 hipError_t pooled_update_prepare();   // once per process, before the first launch_pooled_update
 
 }  // namespace smcmc
